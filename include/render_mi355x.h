@@ -1,0 +1,160 @@
+/*
+ * render_mi355x.h -- C-ABI of librender_mi355x.so, the MI355X (gfx950) drop-in for the
+ * hot path of KVM-Explorer/AscendPathTracing (reference paths are relative to the
+ * reference repository root):
+ *
+ *     ray-generate -> ray/sphere intersect -> mirror-reflect / throughput loop -> colour
+ *
+ * Every entry point below names the reference interface it replaces.  Plain pointers and
+ * sizes only; no C++ or torch types.  All device entry points ENQUEUE work on the HIP
+ * stream they are given and return without synchronising (the caller synchronises, as
+ * src/main.cpp:75 does with aclrtSynchronizeStream); they never allocate, free or retain
+ * memory, so they are legal inside a hipGraph capture.
+ *
+ * Buffers (little-endian IEEE float32):
+ *   rays     [6][N]   planes ox,oy,oz,dx,dy,dz              scripts/gen_data.py:65-71
+ *   spheres  [10][Ns] planes r^2,x,y,z,emX,emY,emZ,colX,colY,colZ, zero padded to a
+ *                     multiple of 512 bytes                  scripts/gen_data.py:106-127
+ *   colors   [3][N]   planes r,g,b                           src/render.cpp:218-220
+ *   path index p = (((i*H + j)*2 + sy)*2 + sx)*S + k         scripts/gen_data.py:32-36
+ *   N = W*H*4*S.
+ */
+#ifndef RENDER_MI355X_H
+#define RENDER_MI355X_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define APT_ABI_VERSION 1
+
+/* status codes returned by the *_ex / frame entry points (render_do itself is void,
+ * like the reference, and reports through apt_last_error()). */
+enum {
+    APT_OK = 0,
+    APT_ERR_ARG = 1,       /* null pointer, zero size, size not representable            */
+    APT_ERR_STRUCT = 2,    /* struct_size does not match this library                    */
+    APT_ERR_SCENE = 3,     /* num_spheres == 0 or light_index out of range               */
+    APT_ERR_DEVICE = 4,    /* HIP runtime error (no device, launch failure, ...)         */
+    APT_ERR_IO = 5         /* file contract helpers                                      */
+};
+
+/* arithmetic modes */
+enum {
+    APT_MODE_KERNEL = 0,   /* K-mode: operation order of src/rt_helper.h, all fp32       */
+    APT_MODE_ORACLE = 1    /* O-mode: scripts/gen_data.py:246-429 test_soa; the two dot  */
+                           /* products of the shading step accumulate in float64 and an  */
+                           /* all-miss selects sphere index -1 (Python wrap-around)      */
+};
+
+/* flags */
+enum {
+    APT_FLAG_RETIRE = 1u   /* result-preserving retirement of finished paths: a path     */
+                           /* whose alive bit is cleared or whose throughput is (0,0,0)   */
+                           /* stops bouncing; colours are bit-identical either way.       */
+};
+
+/* Run-time form of the reference's compile-time constants
+ * (src/common.h:4-14, src/render.cpp:141,194-196, scripts/gen_data.py:6-10). */
+typedef struct apt_render_params {
+    uint32_t struct_size;   /* = sizeof(apt_render_params)                               */
+    uint32_t width;         /* WIDTH   (common.h:4)                                      */
+    uint32_t height;        /* HEIGHT  (common.h:5)                                      */
+    uint32_t samples;       /* SAMPLES (common.h:6); samples per pixel = 4*samples       */
+    uint32_t depth;         /* bounce count, literal 5 at render.cpp:141                 */
+    uint32_t num_spheres;   /* SPHERE_NUM (common.h:10)                                  */
+    int32_t  light_index;   /* literal 7 at rt_helper.h:776 / gen_data.py:381            */
+    float    eps;           /* EPSILON (common.h:9)                                      */
+    float    gain;          /* literal 12 at render.cpp:194-196                          */
+    uint32_t mode;          /* APT_MODE_*                                                */
+    uint32_t flags;         /* APT_FLAG_*                                                */
+    uint32_t reserved;      /* must be 0                                                 */
+    uint64_t path_begin;    /* first path index this call renders (multi-GPU shard)      */
+    uint64_t path_count;    /* number of paths this call renders; 0 = all N              */
+    uint64_t seed;          /* device ray generation only                                */
+} apt_render_params;
+
+/* Fill *p with the reference defaults: 16x16, samples 1, depth 5, 8 spheres, light 7,
+ * eps 1e-4, gain 12, K-mode, no flags, whole image. */
+void apt_default_params(apt_render_params *p);
+
+/* ---- the reference boundary ---------------------------------------------------------
+ * Replaces  void render_do(uint32_t blockDim, void *l2ctrl, void *stream,
+ *                          uint8_t *rays, uint8_t *spheres, uint8_t *colors)
+ * declared at src/main.cpp:9-10, defined at src/render.cpp:262-266 (body:
+ * render<<<blockDim, l2ctrl, stream>>>(rays, spheres, colors)).
+ *   blockDim  number of contiguous partitions in the reference (8); the result does not
+ *             depend on it here, it is accepted and ignored
+ *   l2ctrl    ignored
+ *   stream    hipStream_t (0 = the default stream)
+ *   rays, spheres, colors   DEVICE pointers, sizes 24*N, 512 and 12*N bytes
+ *                           (src/main.cpp:47-49) with the reference's compile-time
+ *                           W=H=16, S=1, depth 5; override with apt_set_default_params.
+ * Asynchronous; errors are recorded for apt_last_error(). */
+void render_do(uint32_t blockDim, void *l2ctrl, void *stream,
+               uint8_t *rays, uint8_t *spheres, uint8_t *colors);
+
+/* The parameters render_do() uses (process-wide).  Returns APT_OK or APT_ERR_*. */
+int apt_set_default_params(const apt_render_params *p);
+
+/* Extended form of the same boundary with run-time parameters.
+ * rays/colors are the FULL [6][N] / [3][N] device buffers; the call reads and writes only
+ * paths [path_begin, path_begin+path_count). */
+int render_do_ex(const apt_render_params *p, void *stream,
+                 const float *rays, const float *spheres, float *colors);
+
+/* ---- rays generated on the device, samples accumulated on the device ----------------
+ * Fuses gen_rays (scripts/gen_data.py:21-75, camera maths in float64, one counter-based
+ * xorshift64* draw pair per path instead of the host MT19937 stream), the render loop
+ * (src/render.cpp:104-207) and decode_color (scripts/data_visualization.py:20-59: mean
+ * over S, sum over the 2x2 sub-pixels in float64, /4, clip, *255 truncation).
+ *   pixel_begin, pixel_count   range of x-major pixel indices q = i*H + j rendered
+ *   fb      device, float32 [3][pixel_count]: clipped pixel value in [0,1], planes r,g,b,
+ *           indexed by q - pixel_begin (y NOT flipped; apt_write_ppm flips)
+ *   fb_u8   device, uint8 [pixel_count][3] = trunc(clip * 255) from the float64 value,
+ *           or NULL
+ * p->path_begin/path_count are ignored here. */
+int render_frame(const apt_render_params *p, void *stream, const float *spheres,
+                 uint64_t pixel_begin, uint64_t pixel_count, float *fb, uint8_t *fb_u8);
+
+/* Device gen_rays with the counter-based generator: writes rays [6][N] planes for paths
+ * [path_begin, path_begin+path_count) of the full buffer (same rays render_frame traces). */
+int apt_gen_rays_device(const apt_render_params *p, void *stream, float *rays);
+
+/* Device decode_color: colors [3][N] -> fb float32 [3][W*H] (+ fb_u8 [W*H][3] or NULL),
+ * same arithmetic as scripts/data_visualization.py:20-59. */
+int apt_decode_color_device(const apt_render_params *p, void *stream, const float *colors,
+                            float *fb, uint8_t *fb_u8);
+
+/* ---- host-side helpers (no GPU) -------------------------------------------------------
+ * Host gen_rays, bit-exact with scripts/gen_data.py:21-75 under np.random.seed(seed)
+ * (MT19937 legacy stream).  rays = HOST float32 [6][N]. */
+int apt_gen_rays_host(uint32_t width, uint32_t height, uint32_t samples, uint32_t seed,
+                      float *rays);
+
+/* Host gen_spheres (scripts/gen_data.py:92-132): writes the 128-float / 512-byte table. */
+int apt_gen_spheres_host(float *spheres128);
+
+/* Build-defined large scene (BASELINE config 4; the reference has no generator):
+ * spheres 0..5 the six walls, 6..Ns-2 random small spheres, Ns-1 the light.
+ * Writes [10][Ns] planes zero padded to a multiple of 128 floats; *out_floats receives the
+ * padded length.  Pass spheres == NULL to query the length. */
+int apt_gen_scene_host(uint32_t num_spheres, uint64_t seed, float *spheres,
+                       size_t *out_floats);
+
+/* P3 writer of scripts/data_visualization.py:11-17 from a [pixel][3] uint8 image in
+ * x-major pixel order (q = i*H + j, y not flipped). */
+int apt_write_ppm(const char *path, uint32_t width, uint32_t height, const uint8_t *fb_u8);
+
+/* ---- diagnostics ------------------------------------------------------------------- */
+int         apt_abi_version(void);
+const char *apt_last_error(void);       /* thread-local, "" when none */
+int         apt_device_count(void);     /* number of HIP devices, 0 when none */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RENDER_MI355X_H */
