@@ -1,0 +1,159 @@
+// host_helpers.cpp -- host-side entry points of librender_mi355x.so that need no GPU:
+//   apt_gen_rays_host     scripts/gen_data.py:21-75   gen_rays (MT19937 legacy stream, float64 camera)
+//   apt_gen_spheres_host  scripts/gen_data.py:92-132  gen_spheres
+//   apt_gen_scene_host    build-defined large scene (BASELINE config 4; no reference counterpart)
+//   apt_write_ppm         scripts/data_visualization.py:11-17 write_ppm
+// Compiled with -ffp-contract=off like the kernels (shared arithmetic: pt_core.h).
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/render_mi355x.h"
+#include "pt_core.h"
+
+namespace {
+
+// np.random.seed(s); np.random.rand(): MT19937 (init_genrand) and the 53-bit
+// random_sample construction ((a >> 5) * 2^26 + (b >> 6)) / 2^53.
+class Mt19937 {
+  public:
+    explicit Mt19937(uint32_t seed) {
+        mt_[0] = seed;
+        for (int i = 1; i < kN; ++i) mt_[i] = 1812433253u * (mt_[i - 1] ^ (mt_[i - 1] >> 30)) + (uint32_t)i;
+        pos_ = kN;
+    }
+    uint32_t next32() {
+        if (pos_ >= kN) refill();
+        uint32_t y = mt_[pos_++];
+        y ^= y >> 11;
+        y ^= (y << 7) & 0x9d2c5680u;
+        y ^= (y << 15) & 0xefc60000u;
+        y ^= y >> 18;
+        return y;
+    }
+    double next_double() {
+        const uint32_t a = next32() >> 5, b = next32() >> 6;
+        return (a * 67108864.0 + b) / 9007199254740992.0;
+    }
+
+  private:
+    static constexpr int kN = 624, kM = 397;
+    void refill() {
+        for (int i = 0; i < kN; ++i) {
+            const uint32_t y = (mt_[i] & 0x80000000u) | (mt_[(i + 1) % kN] & 0x7fffffffu);
+            mt_[i] = mt_[(i + kM) % kN] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+        }
+        pos_ = 0;
+    }
+    uint32_t mt_[kN];
+    int pos_;
+};
+
+// The reference scene table, (r, x, y, z, em*3, col*3) per sphere: gen_data.py:94-102.
+const double kSpheres[8][10] = {
+    {1e5, 1e5 + 1, 40.8, 81.6, 0, 0, 0, 0.435, 0.376, 0.667},     // Left
+    {1e5, -1e5 + 99, 40.8, 81.6, 0, 0, 0, 0.667, 0.129, 0.086},   // Right
+    {1e5, 50, 40.8, 1e5, 0, 0, 0, 0.270, 0.725, 0.486},           // Back
+    {1e5, 50, 40.8, -1e5 + 170, 0, 0, 0, 0, 0, 0},                // Front (black)
+    {1e5, 50, 1e5, 81.6, 0, 0, 0, 0.5, 0.5, 0.5},                 // Bottom
+    {1e5, 50, -1e5 + 81.6, 81.6, 0, 0, 0, 0.141, 0.408, 0.635},   // Top
+    {16.5, 27, 16.5, 47, 0, 0, 0, 0.999, 0.999, 0.999},           // Mirror
+    {600, 50, 681.6 - 0.27, 81.6, 12, 12, 12, 0, 0, 0}};          // Light
+
+void sphere_record(int k, float rec[10]) {
+    for (int m = 0; m < 10; ++m) {
+        double v = kSpheres[k][m];
+        if (m == 0) v = v * v; // gen_data.py:109: r -> r^2 in float64, float32 only at tofile (:127)
+        rec[m] = (float)v;
+    }
+}
+
+size_t padded_floats(size_t n) { return (n + 127) / 128 * 128; } // gen_data.py:120-127: 512-byte multiple
+
+} // namespace
+
+extern "C" {
+
+int apt_gen_rays_host(uint32_t width, uint32_t height, uint32_t samples, uint32_t seed, float *rays) {
+    if (!rays || !width || !height || !samples) return APT_ERR_ARG;
+    Mt19937 rng(seed); // np.random.seed(0): gen_data.py:438
+    apt::Camera cam;
+    apt::camera_init(cam, width, height);
+    const uint64_t n = (uint64_t)width * height * 4u * samples;
+    uint64_t p = 0;
+    for (uint32_t i = 0; i < width; ++i)               // gen_data.py:32-36 loop nest
+        for (uint32_t j = 0; j < height; ++j)
+            for (uint32_t sy = 0; sy < 2; ++sy)
+                for (uint32_t sx = 0; sx < 2; ++sx)
+                    for (uint32_t k = 0; k < samples; ++k, ++p) {
+                        const double u1 = rng.next_double(); // r1 before r2: :37,:39
+                        const double u2 = rng.next_double();
+                        float ray[6];
+                        apt::camera_ray(cam, width, height, i, j, sy, sx, u1, u2, ray);
+                        for (int m = 0; m < 6; ++m) rays[(uint64_t)m * n + p] = ray[m]; // SoA: :65-71
+                    }
+    return APT_OK;
+}
+
+int apt_gen_spheres_host(float *spheres128) {
+    if (!spheres128) return APT_ERR_ARG;
+    memset(spheres128, 0, 128 * sizeof(float));
+    for (int k = 0; k < 8; ++k) {
+        float rec[10];
+        sphere_record(k, rec);
+        for (int m = 0; m < 10; ++m) spheres128[m * 8 + k] = rec[m]; // transpose to planes: :113
+    }
+    return APT_OK;
+}
+
+int apt_gen_scene_host(uint32_t num_spheres, uint64_t seed, float *spheres, size_t *out_floats) {
+    if (num_spheres < 8) return APT_ERR_SCENE;
+    const size_t total = padded_floats((size_t)num_spheres * 10);
+    if (out_floats) *out_floats = total;
+    if (!spheres) return APT_OK;
+    memset(spheres, 0, total * sizeof(float));
+    for (uint32_t k = 0; k < num_spheres; ++k) {
+        float rec[10];
+        if (k < 6) sphere_record((int)k, rec);                 // the six walls
+        else if (k == num_spheres - 1) sphere_record(7, rec);  // the light keeps index Ns-1
+        else {                                                 // small random spheres inside the room
+            uint64_t s = apt::splitmix64(seed ^ apt::splitmix64(0x5CE7E000ull + k));
+            if (s == 0) s = 0x9E3779B97F4A7C15ull;
+            double u[7];
+            for (int m = 0; m < 7; ++m) u[m] = (double)(apt::xorshift64s(s) >> 11) * (1.0 / 9007199254740992.0);
+            const double r = 0.5 + 1.5 * u[0];
+            rec[0] = (float)(r * r);
+            rec[1] = (float)(1.0 + 98.0 * u[1]);
+            rec[2] = (float)(81.6 * u[2]);
+            rec[3] = (float)(170.0 * u[3]);
+            rec[4] = rec[5] = rec[6] = 0.0f;
+            rec[7] = (float)(0.1 + 0.899 * u[4]);
+            rec[8] = (float)(0.1 + 0.899 * u[5]);
+            rec[9] = (float)(0.1 + 0.899 * u[6]);
+        }
+        for (int m = 0; m < 10; ++m) spheres[(size_t)m * num_spheres + k] = rec[m];
+    }
+    return APT_OK;
+}
+
+// write_ppm: the reference's loop `for i in range(w): for j in range(h): data[j, i]` over the
+// (w,h,3) array returned by decode_color (second index already y-flipped) emits file row i
+// = image row y = h-1-i and file column j = x.  It only stays in range for w == h; the
+// non-square case is defined here the evident way, h rows of w pixels.
+int apt_write_ppm(const char *path, uint32_t width, uint32_t height, const uint8_t *fb_u8) {
+    if (!path || !fb_u8 || !width || !height) return APT_ERR_ARG;
+    FILE *f = fopen(path, "w");
+    if (!f) return APT_ERR_IO;
+    fprintf(f, "P3\n%u %u\n255\n", width, height);
+    for (uint32_t row = 0; row < height; ++row) {
+        const uint32_t y = height - 1 - row;
+        for (uint32_t x = 0; x < width; ++x) {
+            const uint8_t *px = fb_u8 + ((uint64_t)x * height + y) * 3;
+            fprintf(f, "%u %u %u ", px[0], px[1], px[2]);
+        }
+        fprintf(f, "\n");
+    }
+    return fclose(f) == 0 ? APT_OK : APT_ERR_IO;
+}
+
+} // extern "C"

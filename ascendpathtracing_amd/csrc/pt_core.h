@@ -1,0 +1,219 @@
+// pt_core.h -- arithmetic of the hot path, shared by the gfx950 kernels and the host-side
+// helpers of librender_mi355x.so.  Compiled with -ffp-contract=off: every fp32 operation in
+// this file is one separately rounded IEEE operation, in the reference's order, because the
+// demo scene (r = 1e5 spheres in fp32) amplifies a single differently rounded bit into a
+// different path.  fma() appears only where the reference's NumPy
+// provably uses one (float64 ddot inside np.linalg.norm).
+//
+// Reference (paths relative to the reference repository root):
+//   intersect_sphere     src/rt_helper.h:255-370  SphereHitInfo
+//   running arg-min      src/rt_helper.h:372-451  Transpose + ReduceMinInfo (lowest index on ties)
+//   shade_and_reflect    src/rt_helper.h:504-709  GenerateNewRays, :711-830 AccumulateIntervalColor
+//   O-mode variants      scripts/gen_data.py:336-349 (np.linalg.norm / np.dot accumulate in float64)
+//   camera / tent / ray  scripts/gen_data.py:21-75  gen_rays
+#pragma once
+#include <stdint.h>
+#include <math.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define APT_HD __host__ __device__ __forceinline__
+#else
+#define APT_HD inline
+#endif
+
+namespace apt {
+
+constexpr int kModeKernel = 0;  // APT_MODE_KERNEL
+constexpr int kModeOracle = 1;  // APT_MODE_ORACLE
+constexpr float kMissT = 1e20f; // rt_helper.h:363, gen_data.py:242
+
+// ---- ray / sphere -------------------------------------------------------------------
+// Distance along the ray to sphere (c, r2), or kMissT.  rt_helper.h:263-363.
+APT_HD float intersect_sphere(float cx, float cy, float cz, float r2, float ox, float oy, float oz, float dx, float dy,
+                              float dz, float eps) {
+    float ocx = cx - ox, ocy = cy - oy, ocz = cz - oz;  // :263-268  -(o + (-c)) == c - o exactly
+    // :273,:297 the kernel starts b and c from Duplicate(0); 0 + x is exact except that it
+    // turns a -0.0 first product into +0.0, which cannot change t (b enters only through
+    // b*b and b -/+ q), so the addition is omitted here, as in sim_npu (gen_data.py:206-207).
+    float b = ocx * dx;                                 // :278-280  FakeMulAddDst = mul, then add
+    b = b + ocy * dy;
+    b = b + ocz * dz;
+    float c = ocx * ocx;                                // :301-303
+    c = c + ocy * ocy;
+    c = c + ocz * ocz;
+    c = c - r2;                                         // :304
+    float disc = b * b;                                 // :314
+    disc = disc - c;                                    // :315
+    float q = sqrtf(disc);                              // :325 correctly rounded; NaN when disc < 0
+    float t0 = b - q, t1 = b + q;                       // :330-331
+    float t = (t0 > eps) ? t0 : t1;                     // :341 FakeSelect (NaN compares false)
+    return (t > eps) ? t : kMissT;                      // :349,:363
+}
+
+// Discriminant only (same operations, same order) for the large-scene traversal, which
+// skips the sqrt when no lane of the wave can hit: a miss contributes kMissT, which never
+// wins the strict '<' arg-min, so skipping it is result preserving.
+struct HitPre { float b, disc; };
+APT_HD HitPre intersect_pre(float cx, float cy, float cz, float r2, float ox, float oy, float oz, float dx, float dy,
+                            float dz) {
+    float ocx = cx - ox, ocy = cy - oy, ocz = cz - oz;
+    float b = ocx * dx;
+    b = b + ocy * dy;
+    b = b + ocz * dz;
+    float c = ocx * ocx;
+    c = c + ocy * ocy;
+    c = c + ocz * ocz;
+    c = c - r2;
+    float disc = b * b;
+    disc = disc - c;
+    return {b, disc};
+}
+APT_HD float intersect_post(HitPre h, float eps) {
+    float q = sqrtf(h.disc);
+    float t0 = h.b - q, t1 = h.b + q;
+    float t = (t0 > eps) ? t0 : t1;
+    return (t > eps) ? t : kMissT;
+}
+
+// State of one path between bounces.
+struct PathState {
+    float ox, oy, oz, dx, dy, dz; // ray (updated in place, rt_helper.h:699-708)
+    float rx, ry, rz;             // throughput `ret` (render.cpp:116-121)
+    bool alive;                   // retMask bit (render.cpp:123-124)
+};
+
+APT_HD void path_init(PathState &s, float ox, float oy, float oz, float dx, float dy, float dz) {
+    s.ox = ox; s.oy = oy; s.oz = oz; s.dx = dx; s.dy = dy; s.dz = dz;
+    s.rx = 1.0f; s.ry = 1.0f; s.rz = 1.0f;
+    s.alive = true;
+}
+
+// A finished path: nothing a further bounce does can change its colour (Appendix A notes).
+APT_HD bool path_finished(const PathState &s) {
+    return !s.alive || (s.rx == 0.0f && s.ry == 0.0f && s.rz == 0.0f);
+}
+
+// GenerateNewRays + AccumulateIntervalColor for the hit (tmin, sphere centre c, albedo col).
+// is_light: the arg-min index equals light_index.
+template <int MODE>
+APT_HD void shade_and_reflect(PathState &s, float tmin, float cx, float cy, float cz, float colx, float coly,
+                              float colz, bool is_light) {
+    float hx = s.dx * tmin, hy = s.dy * tmin, hz = s.dz * tmin; // rt_helper.h:513-518
+    hx = s.ox + hx; hy = s.oy + hy; hz = s.oz + hz;
+    float nx = hx - cx, ny = hy - cy, nz = hz - cz;             // :635-637
+    float L;
+    if (MODE == kModeOracle) {                                  // np.linalg.norm, gen_data.py:347
+        float p0 = nx * nx, p1 = ny * ny, p2 = nz * nz;
+        double acc = 0.0 + (double)p0;                          // sdot: double dot = 0.0; dot += y*x
+        acc = acc + (double)p1;
+        acc = acc + (double)p2;
+        L = sqrtf((float)acc);
+    } else {
+        float acc = 0.0f + nx * nx;                             // :641 Duplicate(0), :647-649
+        acc = acc + ny * ny;
+        acc = acc + nz * nz;
+        L = sqrtf(acc);                                         // :658
+    }
+    float ux = nx / L, uy = ny / L, uz = nz / L;                // :664-666 IEEE divide
+    float dot;
+    if (MODE == kModeOracle) {                                  // np.dot, gen_data.py:349
+        float p0 = s.dx * ux, p1 = s.dy * uy, p2 = s.dz * uz;
+        double acc = 0.0 + (double)p0;
+        acc = acc + (double)p1;
+        acc = acc + (double)p2;
+        dot = (float)acc;
+    } else {
+        dot = 0.0f + s.dx * ux;                                 // :690 Duplicate(0), :694-696
+        dot = dot + s.dy * uy;
+        dot = dot + s.dz * uz;
+    }
+    float k2 = dot * 2.0f;                                      // :697
+    float mx = ux * k2, my = uy * k2, mz = uz * k2;             // :699-701
+    s.dx = s.dx - mx; s.dy = s.dy - my; s.dz = s.dz - mz;       // :702-704
+    s.ox = hx; s.oy = hy; s.oz = hz;                            // :706-708
+    s.alive = s.alive && !is_light;                             // :773-787
+    if (s.alive) {                                              // :799-810 (x1 is exact otherwise)
+        s.rx = colx * s.rx; s.ry = coly * s.ry; s.rz = colz * s.rz;
+    }
+}
+
+// ---- ray generation (all float64, cast to float32 at the end: gen_data.py:71) ---------
+struct Camera { double pos[3], g[3], cx[3], cy[3]; };
+
+APT_HD double norm3(double x, double y, double z) { // np.linalg.norm: sqrt(ddot); ddot is an FMA chain
+    double acc = x * x;
+    acc = fma(y, y, acc);
+    acc = fma(z, z, acc);
+    return sqrt(acc);
+}
+
+inline void camera_init(Camera &c, uint32_t w, uint32_t h) { // gen_data.py:24-30
+    c.pos[0] = 50; c.pos[1] = 52; c.pos[2] = 295.6;
+    const double dir[3] = {0, -0.042612, -1};
+    const double n = norm3(dir[0], dir[1], dir[2]);
+    for (int i = 0; i < 3; ++i) c.g[i] = dir[i] / n;
+    c.cx[0] = (double)w * 0.5135 / (double)h; c.cx[1] = 0; c.cx[2] = 0;
+    double cr[3];                                             // np.cross(cx, g)
+    cr[0] = c.cx[1] * c.g[2] - c.cx[2] * c.g[1];
+    cr[1] = c.cx[2] * c.g[0] - c.cx[0] * c.g[2];
+    cr[2] = c.cx[0] * c.g[1] - c.cx[1] * c.g[0];
+    const double cn = norm3(cr[0], cr[1], cr[2]);
+    for (int i = 0; i < 3; ++i) c.cy[i] = cr[i] / cn * 0.5135;
+}
+
+APT_HD double tent(double u) { // gen_data.py:37-40
+    double r = 2 * u;
+    return (r < 1) ? sqrt(r) - 1 : 1 - sqrt(2 - r);
+}
+
+APT_HD void camera_ray(const Camera &c, uint32_t w, uint32_t h, uint32_t i, uint32_t j, uint32_t sy, uint32_t sx,
+                       double u1, double u2, float ray[6]) {
+    double ddx = tent(u1), ddy = tent(u2);
+    double a = (((double)sx + 0.5 + ddx) / 2 + (double)i) / (double)w - 0.5; // :41
+    double b = (((double)sy + 0.5 + ddy) / 2 + (double)j) / (double)h - 0.5; // :42
+    double d0 = (c.cx[0] * a + c.cy[0] * b) + c.g[0];
+    double d1 = (c.cx[1] * a + c.cy[1] * b) + c.g[1];
+    double d2 = (c.cx[2] * a + c.cy[2] * b) + c.g[2];
+    double n = norm3(d0, d1, d2);
+    ray[0] = (float)(c.pos[0] + d0 * 140);                                   // :45
+    ray[1] = (float)(c.pos[1] + d1 * 140);
+    ray[2] = (float)(c.pos[2] + d2 * 140);
+    ray[3] = (float)(d0 / n);                                                // :46
+    ray[4] = (float)(d1 / n);
+    ray[5] = (float)(d2 / n);
+}
+
+// Counter-based generator for on-device ray generation: splitmix64 of (seed, path index)
+// seeds one xorshift64* stream; two 53-bit uniforms per path.  Integer-only, so host and
+// device agree bit for bit.
+APT_HD uint64_t splitmix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+APT_HD uint64_t xorshift64s(uint64_t &s) {
+    uint64_t x = s;
+    x ^= x >> 12; x ^= x << 25; x ^= x >> 27;
+    s = x;
+    return x * 0x2545F4914F6CDD1Dull;
+}
+APT_HD void path_uniforms(uint64_t seed, uint64_t path, double &u1, double &u2) {
+    uint64_t s = splitmix64(seed ^ splitmix64(path));
+    if (s == 0) s = 0x9E3779B97F4A7C15ull;
+    u1 = (double)(xorshift64s(s) >> 11) * (1.0 / 9007199254740992.0);
+    u2 = (double)(xorshift64s(s) >> 11) * (1.0 / 9007199254740992.0);
+}
+
+// path index -> (i, j, sy, sx, k):  p = (((i*H + j)*2 + sy)*2 + sx)*S + k   gen_data.py:32-36
+APT_HD void path_coords(uint64_t p, uint32_t H, uint32_t S, uint32_t &i, uint32_t &j, uint32_t &sy, uint32_t &sx) {
+    uint64_t r = p / S;
+    sx = (uint32_t)(r & 1);
+    sy = (uint32_t)((r >> 1) & 1);
+    r >>= 2;
+    j = (uint32_t)(r % H);
+    i = (uint32_t)(r / H);
+}
+
+} // namespace apt

@@ -1,0 +1,586 @@
+// render_kernels.hip -- gfx950 (MI355X, wave64) kernels of the path-tracing hot path and
+// the C-ABI of librender_mi355x.so (include/render_mi355x.h).
+//
+// One lane = one path; the whole bounce loop lives in registers (the reference moves 64-ray
+// tiles through a 16 KB scratch buffer with a free-list allocator, src/allocator.h -- no
+// counterpart here).  No MFMA: this is branchy fp32 VALU work.  Built with
+// -ffp-contract=off (see pt_core.h) so that results are bitwise those of the CPU
+// restatement; sqrt and divide are hipcc's correctly rounded expansions.
+//
+// Kernels
+//   render_paths_kernel   rays from a [6][N] buffer -> colours [3][N]
+//                         = src/render.cpp:40-60,82-223 (Process/CopyIn/Compute/CopyOut)
+//   render_frame_kernel   ray-generate + trace + per-pixel accumulation, nothing
+//                         materialised = gen_data.py:21-75 + render.cpp:104-207 +
+//                         data_visualization.py:20-59
+//   gen_rays_kernel       device gen_rays (counter RNG)
+//   decode_color_kernel   device decode_color
+//
+// Scene placement
+//   Ns == 8 (the reference scene): the 32 geometry floats are read once per wave with
+//   scalar loads (wave-uniform addresses into a read-only buffer -> s_load into SGPRs) and
+//   every intersect instruction takes its sphere operand from an SGPR; centre/albedo of the
+//   hit sphere are gathered per lane from a 256-byte LDS table (8 distinct 16-byte slots,
+//   conflict free).
+//   Any Ns: [cx,cy,cz,r2] tiles of 1024 spheres are staged through LDS by the whole
+//   workgroup (coalesced plane loads) and read back as wave-uniform ds_read_b128
+//   broadcasts; the sqrt half of the intersection is skipped when no lane of the wave has a
+//   non-negative discriminant.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+#include "../../include/render_mi355x.h"
+#include "pt_core.h"
+
+namespace {
+
+using namespace apt;
+
+constexpr int kBlock = 256;      // 4 waves
+constexpr int kTile = 1024;      // spheres per LDS tile (16 KB)
+constexpr int kMaxLeaves = 64;   // pairwise-sum leaves -> samples <= 8192
+constexpr int kMaxStack = 8;
+
+struct Scene8 { // wave-uniform registers (SGPRs)
+    float cx[8], cy[8], cz[8], r2[8];
+};
+
+struct TraceArgs {
+    uint32_t ns;
+    uint32_t depth;
+    int32_t light;
+    float eps, gain;
+    unsigned long long *traced; // optional device counter of traced segments
+};
+
+struct LeafProg { // numpy pairwise_sum recursion flattened (see build_leaves)
+    uint32_t nleaves;
+    uint16_t len[kMaxLeaves];
+    uint8_t ncomb[kMaxLeaves];
+};
+
+// ---- trace: reference scene (Ns == 8) ----------------------------------------------------
+template <int MODE, bool RETIRE>
+__device__ __forceinline__ uint32_t trace_ns8(const Scene8 &sc, const float4 *tab, PathState &s, bool valid,
+                                              const TraceArgs &ta) {
+    uint32_t traced = 0;
+    for (uint32_t d = 0; d < ta.depth; ++d) { // render.cpp:140-188
+        const bool fin = !valid || (RETIRE && path_finished(s));
+        if (RETIRE && __all(fin)) break;
+        float tmin = kMissT;
+        int idx = (MODE == kModeOracle) ? -1 : 0; // all-miss: gen_data.py:311 / rt_helper.h:183-201
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { // rt_helper.h:457-467
+            const float t = intersect_sphere(sc.cx[k], sc.cy[k], sc.cz[k], sc.r2[k], s.ox, s.oy, s.oz, s.dx, s.dy,
+                                             s.dz, ta.eps);
+            if (t < tmin) { tmin = t; idx = k; } // strict '<', ascending k: lowest index wins ties
+        }
+        const int g = (idx < 0) ? 7 : idx; // Python index -1 wraps to the last sphere
+        const float4 c = tab[2 * g], col = tab[2 * g + 1];
+        PathState n = s;
+        shade_and_reflect<MODE>(n, tmin, c.x, c.y, c.z, col.x, col.y, col.z, idx == ta.light);
+        if (!fin) { s = n; ++traced; }
+    }
+    return traced;
+}
+
+// ---- trace: any scene, LDS-staged tiles -------------------------------------------------
+// Every thread of the workgroup must call this together (it contains barriers).
+template <int MODE, bool RETIRE>
+__device__ __forceinline__ uint32_t trace_dyn(const float *__restrict__ sph, float4 *tile, PathState &s, bool valid,
+                                              const TraceArgs &ta) {
+    const uint32_t ns = ta.ns;
+    const float *r2 = sph, *cx = sph + ns, *cy = sph + 2 * (size_t)ns, *cz = sph + 3 * (size_t)ns;
+    const float *colx = sph + 7 * (size_t)ns, *coly = sph + 8 * (size_t)ns, *colz = sph + 9 * (size_t)ns;
+    uint32_t traced = 0;
+    for (uint32_t d = 0; d < ta.depth; ++d) {
+        const bool fin = !valid || (RETIRE && path_finished(s));
+        if (RETIRE && __syncthreads_and(fin)) break;
+        float tmin = kMissT;
+        int idx = (MODE == kModeOracle) ? -1 : 0;
+        for (uint32_t base = 0; base < ns; base += kTile) {
+            const uint32_t n = min((uint32_t)kTile, ns - base);
+            __syncthreads(); // previous tile fully consumed
+            for (uint32_t k = threadIdx.x; k < n; k += kBlock)
+                tile[k] = make_float4(cx[base + k], cy[base + k], cz[base + k], r2[base + k]);
+            __syncthreads();
+            for (uint32_t k = 0; k < n; ++k) {
+                const float4 sp = tile[k]; // wave-uniform address: LDS broadcast
+                const HitPre h = intersect_pre(sp.x, sp.y, sp.z, sp.w, s.ox, s.oy, s.oz, s.dx, s.dy, s.dz);
+                if (__any(h.disc >= 0.0f)) { // a negative discriminant yields kMissT, which never wins
+                    const float t = intersect_post(h, ta.eps);
+                    if (t < tmin) { tmin = t; idx = (int)(base + k); }
+                }
+            }
+        }
+        const uint32_t g = (idx < 0) ? ns - 1 : (uint32_t)idx;
+        PathState n = s;
+        shade_and_reflect<MODE>(n, tmin, cx[g], cy[g], cz[g], colx[g], coly[g], colz[g], idx == ta.light);
+        if (!fin) { s = n; ++traced; }
+    }
+    return traced;
+}
+
+// spheres.bin layout [10][8]: r2, x, y, z, em*3, col*3 (gen_data.py:106-127, rt_helper.h:93-102)
+__device__ __forceinline__ void load_scene8(const float *__restrict__ sph, Scene8 &sc, float4 *tab) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { // constant offsets from a uniform read-only pointer: scalar loads
+        sc.r2[k] = sph[k]; sc.cx[k] = sph[8 + k]; sc.cy[k] = sph[16 + k]; sc.cz[k] = sph[24 + k];
+    }
+    if (threadIdx.x < 8) {
+        const int k = threadIdx.x;
+        tab[2 * k] = make_float4(sph[8 + k], sph[16 + k], sph[24 + k], sph[k]);
+        tab[2 * k + 1] = make_float4(sph[56 + k], sph[64 + k], sph[72 + k], 0.0f);
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ void count_traced(const TraceArgs &ta, uint32_t traced) {
+    if (ta.traced) { // one atomic per wave
+        unsigned long long t = traced;
+        for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off, 64);
+        if ((threadIdx.x & 63) == 0 && t) atomicAdd(ta.traced, t);
+    }
+}
+
+// ---- kernel: rays from a buffer ---------------------------------------------------------
+template <int MODE, bool NS8, bool RETIRE>
+__global__ __launch_bounds__(kBlock) void render_paths_kernel(const float *__restrict__ rays,
+                                                              const float *__restrict__ sph,
+                                                              float *__restrict__ colors, uint64_t n_total,
+                                                              uint64_t begin, uint64_t count, TraceArgs ta) {
+    __shared__ float4 tab[16];
+    __shared__ float4 tile[NS8 ? 1 : kTile];
+    Scene8 sc;
+    if (NS8) load_scene8(sph, sc, tab);
+    const uint64_t local = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    const bool valid = local < count;
+    const uint64_t p = begin + (valid ? local : 0);
+    PathState s;                                          // CopyIn: render.cpp:82-101
+    path_init(s, rays[p], rays[n_total + p], rays[2 * n_total + p], rays[3 * n_total + p], rays[4 * n_total + p],
+              rays[5 * n_total + p]);
+    const uint32_t traced = NS8 ? trace_ns8<MODE, RETIRE>(sc, tab, s, valid, ta)
+                                : trace_dyn<MODE, RETIRE>(sph, tile, s, valid, ta);
+    if (valid) {                                          // render.cpp:194-196, CopyOut :210-223
+        colors[p] = s.rx * ta.gain;
+        colors[n_total + p] = s.ry * ta.gain;
+        colors[2 * n_total + p] = s.rz * ta.gain;
+    }
+    count_traced(ta, valid ? traced : 0);
+}
+
+// ---- kernel: fused frame ----------------------------------------------------------------
+struct FrameArgs {
+    Camera cam;
+    uint32_t width, height, samples;
+    uint64_t seed;
+    uint64_t pixel_begin, pixel_count;
+    float *fb;       // [3][pixel_count]
+    uint8_t *fb_u8;  // [pixel_count][3] or null
+};
+
+// GROUP lanes share one sub-pixel: lane j of the group owns numpy's pairwise accumulator
+// r[j] (samples j, 8+j, 16+j, ...), so the summation order of np.mean is reproduced with
+// a 3-step butterfly and no shared memory.  GROUP == 1 serves samples < 8 (numpy sums
+// those sequentially).
+template <int MODE, bool NS8, int GROUP, bool RETIRE>
+__global__ __launch_bounds__(kBlock) void render_frame_kernel(const float *__restrict__ sph, FrameArgs fa,
+                                                              TraceArgs ta, LeafProg lp) {
+    __shared__ float4 tab[16];
+    __shared__ float4 tile[NS8 ? 1 : kTile];
+    extern __shared__ float stack_lds[]; // [kMaxStack][3][kBlock] when lp.nleaves > 1
+    Scene8 sc;
+    if (NS8) load_scene8(sph, sc, tab);
+
+    const uint32_t lane = threadIdx.x & 63;
+    const uint64_t L = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    const uint32_t j = (GROUP == 8) ? (uint32_t)(L & 7) : 0u;
+    const uint32_t sub = (uint32_t)(L / GROUP) & 3u;
+    const uint64_t pl = L / (4 * GROUP);
+    const bool valid = pl < fa.pixel_count;
+    const uint64_t q = fa.pixel_begin + (valid ? pl : 0);
+    const uint32_t pi = (uint32_t)(q / fa.height), pj = (uint32_t)(q % fa.height);
+    const uint32_t sy = sub >> 1, sx = sub & 1;
+    const uint64_t pbase = (q * 4 + sub) * fa.samples;
+    uint32_t traced = 0;
+
+    auto sample = [&](uint32_t k, float c[3]) {
+        double u1, u2;
+        path_uniforms(fa.seed, pbase + k, u1, u2);
+        float ray[6];
+        camera_ray(fa.cam, fa.width, fa.height, pi, pj, sy, sx, u1, u2, ray);
+        PathState s;
+        path_init(s, ray[0], ray[1], ray[2], ray[3], ray[4], ray[5]);
+        traced += NS8 ? trace_ns8<MODE, RETIRE>(sc, tab, s, valid, ta)
+                      : trace_dyn<MODE, RETIRE>(sph, tile, s, valid, ta);
+        c[0] = s.rx * ta.gain; c[1] = s.ry * ta.gain; c[2] = s.rz * ta.gain;
+    };
+
+    float res[3] = {0.0f, 0.0f, 0.0f};
+    uint32_t start = 0;
+    int sp = 0;
+    for (uint32_t leaf = 0; leaf < lp.nleaves; ++leaf) {
+        const uint32_t n = lp.len[leaf];
+        float acc[3], c[3];
+        if (GROUP == 1) { // n < 8: res = 0; res += a[i]
+            acc[0] = acc[1] = acc[2] = 0.0f;
+            for (uint32_t k = 0; k < n; ++k) {
+                sample(start + k, c);
+                acc[0] = acc[0] + c[0]; acc[1] = acc[1] + c[1]; acc[2] = acc[2] + c[2];
+            }
+        } else {          // 8 <= n <= 128: r[j] chains, tree, tail
+            const uint32_t nfull = n & ~7u;
+            sample(start + j, acc);
+            for (uint32_t i8 = 8; i8 < nfull; i8 += 8) {
+                sample(start + i8 + j, c);
+                acc[0] = acc[0] + c[0]; acc[1] = acc[1] + c[1]; acc[2] = acc[2] + c[2];
+            }
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) { // ((r0+r1)+(r2+r3)) + ((r4+r5)+(r6+r7))
+                float v = acc[ch];
+                v = v + __shfl_xor(v, 1, 64);
+                v = v + __shfl_xor(v, 2, 64);
+                v = v + __shfl_xor(v, 4, 64);
+                acc[ch] = v;
+            }
+            const uint32_t nt = n - nfull;
+            if (nt) { // res += a[i] for the n % 8 trailing samples, in order
+                sample(start + nfull + (j < nt ? j : 0), c);
+                for (uint32_t t = 0; t < nt; ++t) {
+#pragma unroll
+                    for (int ch = 0; ch < 3; ++ch) acc[ch] = acc[ch] + __shfl(c[ch], (int)((lane & ~7u) + t), 64);
+                }
+            }
+        }
+        start += n;
+        if (lp.nleaves == 1) {
+            res[0] = acc[0]; res[1] = acc[1]; res[2] = acc[2];
+        } else { // pairwise(left) + pairwise(right), innermost first
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) stack_lds[(sp * 3 + ch) * kBlock + threadIdx.x] = acc[ch];
+            ++sp;
+            for (uint32_t m = 0; m < lp.ncomb[leaf]; ++m) {
+                --sp;
+#pragma unroll
+                for (int ch = 0; ch < 3; ++ch) {
+                    const float a = stack_lds[((sp - 1) * 3 + ch) * kBlock + threadIdx.x];
+                    const float b = stack_lds[(sp * 3 + ch) * kBlock + threadIdx.x];
+                    stack_lds[((sp - 1) * 3 + ch) * kBlock + threadIdx.x] = a + b;
+                }
+            }
+        }
+    }
+    if (lp.nleaves > 1) {
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) res[ch] = stack_lds[ch * kBlock + threadIdx.x];
+    }
+
+    // decode_color: data_visualization.py:36-57
+    const float fs = (float)fa.samples;
+    const int gbase = (int)(lane & ~(uint32_t)(4 * GROUP - 1));
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+        const float mean = res[ch] / fs;            // np.mean: float32 sum / count
+        double acc = 0.0;                           // :38 sum_color = zeros (float64)
+#pragma unroll
+        for (int sq = 0; sq < 4; ++sq) acc = acc + (double)__shfl(mean, gbase + sq * GROUP, 64); // :41-45
+        const double v = acc / 4;                   // :46
+        const double cl = v < 0 ? 0 : (v > 1 ? 1 : v); // :54
+        if (valid && (lane & (4 * GROUP - 1)) == 0) {
+            fa.fb[(uint64_t)ch * fa.pixel_count + pl] = (float)cl;
+            if (fa.fb_u8) fa.fb_u8[pl * 3 + ch] = (uint8_t)(cl * 255); // :55-57 truncation
+        }
+    }
+    count_traced(ta, valid ? traced : 0);
+}
+
+// ---- kernel: device gen_rays (counter RNG) -----------------------------------------------
+__global__ __launch_bounds__(kBlock) void gen_rays_kernel(Camera cam, uint32_t width, uint32_t height,
+                                                          uint32_t samples, uint64_t seed, uint64_t n_total,
+                                                          uint64_t begin, uint64_t count, float *__restrict__ rays) {
+    const uint64_t local = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (local >= count) return;
+    const uint64_t p = begin + local;
+    uint32_t i, j, sy, sx;
+    path_coords(p, height, samples, i, j, sy, sx);
+    double u1, u2;
+    path_uniforms(seed, p, u1, u2);
+    float ray[6];
+    camera_ray(cam, width, height, i, j, sy, sx, u1, u2, ray);
+#pragma unroll
+    for (int m = 0; m < 6; ++m) rays[(uint64_t)m * n_total + p] = ray[m];
+}
+
+// ---- kernel: device decode_color -----------------------------------------------------------
+__device__ float pairwise_leaf(const float *a, uint32_t n) { // numpy pairwise_sum, n <= 128
+    if (n < 8) {
+        float r = 0.0f;
+        for (uint32_t i = 0; i < n; ++i) r = r + a[i];
+        return r;
+    }
+    float r[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) r[k] = a[k];
+    uint32_t i;
+    for (i = 8; i < n - (n % 8); i += 8) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) r[k] = r[k] + a[i + k];
+    }
+    float res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < n; ++i) res = res + a[i];
+    return res;
+}
+
+// one thread per (pixel, channel, sub-pixel); 4 adjacent lanes combine in float64
+__global__ __launch_bounds__(kBlock) void decode_color_kernel(const float *__restrict__ colors, uint32_t samples,
+                                                              uint64_t npix, LeafProg lp, float *__restrict__ fb,
+                                                              uint8_t *__restrict__ fb_u8) {
+    const uint64_t L = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    const uint32_t sub = (uint32_t)(L & 3);
+    const uint64_t pc = L >> 2; // pixel * 3 + channel, channel-major: pc = ch * npix + q
+    const bool valid = pc < 3 * npix;
+    const uint64_t ch = valid ? pc / npix : 0, q = valid ? pc % npix : 0;
+    const uint64_t n_total = npix * 4 * samples;
+    const float *a = colors + ch * n_total + (q * 4 + sub) * samples;
+    float st[kMaxStack];
+    int sp = 0;
+    uint32_t start = 0;
+    for (uint32_t leaf = 0; leaf < lp.nleaves; ++leaf) {
+        st[sp++] = pairwise_leaf(a + start, lp.len[leaf]);
+        start += lp.len[leaf];
+        for (uint32_t m = 0; m < lp.ncomb[leaf]; ++m) { --sp; st[sp - 1] = st[sp - 1] + st[sp]; }
+    }
+    const float mean = st[0] / (float)samples;
+    const int gbase = (int)((threadIdx.x & 63) & ~3u);
+    double acc = 0.0;
+#pragma unroll
+    for (int sq = 0; sq < 4; ++sq) acc = acc + (double)__shfl(mean, gbase + sq, 64);
+    const double v = acc / 4;
+    const double cl = v < 0 ? 0 : (v > 1 ? 1 : v);
+    if (valid && sub == 0) {
+        fb[ch * npix + q] = (float)cl;
+        if (fb_u8) fb_u8[q * 3 + ch] = (uint8_t)(cl * 255);
+    }
+}
+
+// ---- host side ----------------------------------------------------------------------------
+thread_local std::string g_err;
+apt_render_params g_default;
+bool g_default_init = false;
+unsigned long long *g_trace_counter = nullptr;
+
+int fail(int code, const char *fmt, const char *detail = "") {
+    char buf[256];
+    snprintf(buf, sizeof buf, fmt, detail);
+    g_err = buf;
+    return code;
+}
+
+void build_leaves(uint32_t n, std::vector<std::pair<uint32_t, uint32_t>> &out) {
+    if (n <= 128) { out.push_back({n, 0u}); return; }
+    uint32_t n2 = n / 2;
+    n2 -= n2 % 8;
+    build_leaves(n2, out);
+    build_leaves(n - n2, out);
+    out.back().second += 1;
+}
+
+int make_leaf_prog(uint32_t samples, LeafProg &lp) {
+    std::vector<std::pair<uint32_t, uint32_t>> v;
+    build_leaves(samples, v);
+    if (v.size() > (size_t)kMaxLeaves) return fail(APT_ERR_ARG, "samples too large for the pairwise plan (max 8192)%s");
+    memset(&lp, 0, sizeof lp);
+    lp.nleaves = (uint32_t)v.size();
+    for (size_t i = 0; i < v.size(); ++i) { lp.len[i] = (uint16_t)v[i].first; lp.ncomb[i] = (uint8_t)v[i].second; }
+    return APT_OK;
+}
+
+int check_params(const apt_render_params *p) {
+    if (!p) return fail(APT_ERR_ARG, "params is null%s");
+    if (p->struct_size != sizeof(apt_render_params)) return fail(APT_ERR_STRUCT, "apt_render_params.struct_size mismatch%s");
+    if (!p->width || !p->height || !p->samples) return fail(APT_ERR_ARG, "width/height/samples must be non-zero%s");
+    if (p->mode > APT_MODE_ORACLE) return fail(APT_ERR_ARG, "unknown mode%s");
+    if (p->num_spheres == 0) return fail(APT_ERR_SCENE, "num_spheres is 0%s");
+    if (p->light_index >= (int32_t)p->num_spheres) return fail(APT_ERR_SCENE, "light_index out of range%s");
+    return APT_OK;
+}
+
+int hip_fail(hipError_t e) { return fail(APT_ERR_DEVICE, "HIP: %s", hipGetErrorString(e)); }
+
+TraceArgs make_trace_args(const apt_render_params *p) {
+    TraceArgs ta;
+    ta.ns = p->num_spheres; ta.depth = p->depth; ta.light = p->light_index;
+    ta.eps = p->eps; ta.gain = p->gain; ta.traced = g_trace_counter;
+    return ta;
+}
+
+template <int MODE, bool NS8>
+void launch_paths(bool retire, dim3 grid, hipStream_t st, const float *rays, const float *sph, float *colors,
+                  uint64_t n, uint64_t b, uint64_t c, const TraceArgs &ta) {
+    if (retire) hipLaunchKernelGGL((render_paths_kernel<MODE, NS8, true>), grid, dim3(kBlock), 0, st, rays, sph, colors, n, b, c, ta);
+    else hipLaunchKernelGGL((render_paths_kernel<MODE, NS8, false>), grid, dim3(kBlock), 0, st, rays, sph, colors, n, b, c, ta);
+}
+
+template <int MODE, bool NS8, int GROUP>
+void launch_frame(bool retire, dim3 grid, size_t lds, hipStream_t st, const float *sph, const FrameArgs &fa,
+                  const TraceArgs &ta, const LeafProg &lp) {
+    if (retire) hipLaunchKernelGGL((render_frame_kernel<MODE, NS8, GROUP, true>), grid, dim3(kBlock), lds, st, sph, fa, ta, lp);
+    else hipLaunchKernelGGL((render_frame_kernel<MODE, NS8, GROUP, false>), grid, dim3(kBlock), lds, st, sph, fa, ta, lp);
+}
+
+template <int MODE, bool NS8>
+void launch_frame_g(int group, bool retire, dim3 grid, size_t lds, hipStream_t st, const float *sph,
+                    const FrameArgs &fa, const TraceArgs &ta, const LeafProg &lp) {
+    if (group == 8) launch_frame<MODE, NS8, 8>(retire, grid, lds, st, sph, fa, ta, lp);
+    else launch_frame<MODE, NS8, 1>(retire, grid, lds, st, sph, fa, ta, lp);
+}
+
+} // namespace
+
+// =============================== C-ABI ======================================================
+extern "C" {
+
+int apt_abi_version(void) { return APT_ABI_VERSION; }
+const char *apt_last_error(void) { return g_err.c_str(); }
+
+int apt_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n;
+}
+
+void apt_default_params(apt_render_params *p) {
+    if (!p) return;
+    memset(p, 0, sizeof *p);
+    p->struct_size = sizeof *p;
+    p->width = 16; p->height = 16; p->samples = 1; // common.h:4-6
+    p->depth = 5;                                   // render.cpp:141
+    p->num_spheres = 8; p->light_index = 7;         // common.h:10, rt_helper.h:776
+    p->eps = 1e-4f; p->gain = 12.0f;                // common.h:9, render.cpp:194
+    p->mode = APT_MODE_KERNEL;
+}
+
+int apt_set_default_params(const apt_render_params *p) {
+    int rc = check_params(p);
+    if (rc) return rc;
+    g_default = *p;
+    g_default_init = true;
+    return APT_OK;
+}
+
+int apt_set_trace_counter(uint64_t *device_counter) {
+    g_trace_counter = (unsigned long long *)device_counter;
+    return APT_OK;
+}
+
+int render_do_ex(const apt_render_params *p, void *stream, const float *rays, const float *spheres, float *colors) {
+    int rc = check_params(p);
+    if (rc) return rc;
+    if (!rays || !spheres || !colors) return fail(APT_ERR_ARG, "rays/spheres/colors must be non-null%s");
+    const uint64_t n = (uint64_t)p->width * p->height * 4u * p->samples;
+    const uint64_t b = p->path_begin;
+    if (b > n) return fail(APT_ERR_ARG, "path_begin beyond the image%s");
+    const uint64_t c = p->path_count ? p->path_count : n - b;
+    if (b + c > n) return fail(APT_ERR_ARG, "path range beyond the image%s");
+    if (c == 0) return APT_OK;
+    const uint64_t blocks = (c + kBlock - 1) / kBlock;
+    if (blocks > 0x7fffffffull) return fail(APT_ERR_ARG, "path_count too large for one launch; shard it%s");
+    hipStream_t st = (hipStream_t)stream;
+    const bool ns8 = p->num_spheres == 8;
+    const TraceArgs ta = make_trace_args(p);
+    const bool retire = p->flags & APT_FLAG_RETIRE;
+    const dim3 grid((unsigned)blocks);
+    if (p->mode == APT_MODE_ORACLE) {
+        if (ns8) launch_paths<kModeOracle, true>(retire, grid, st, rays, spheres, colors, n, b, c, ta);
+        else launch_paths<kModeOracle, false>(retire, grid, st, rays, spheres, colors, n, b, c, ta);
+    } else {
+        if (ns8) launch_paths<kModeKernel, true>(retire, grid, st, rays, spheres, colors, n, b, c, ta);
+        else launch_paths<kModeKernel, false>(retire, grid, st, rays, spheres, colors, n, b, c, ta);
+    }
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? APT_OK : hip_fail(e);
+}
+
+void render_do(uint32_t blockDim, void *l2ctrl, void *stream, uint8_t *rays, uint8_t *spheres, uint8_t *colors) {
+    (void)blockDim; // the reference's 8-way partition (render.cpp:9-10,24): results do not depend on it
+    (void)l2ctrl;
+    if (!g_default_init) { apt_default_params(&g_default); g_default_init = true; }
+    (void)render_do_ex(&g_default, stream, (const float *)rays, (const float *)spheres, (float *)colors);
+}
+
+int render_frame(const apt_render_params *p, void *stream, const float *spheres, uint64_t pixel_begin,
+                 uint64_t pixel_count, float *fb, uint8_t *fb_u8) {
+    int rc = check_params(p);
+    if (rc) return rc;
+    if (!spheres || !fb) return fail(APT_ERR_ARG, "spheres/fb must be non-null%s");
+    const uint64_t npix = (uint64_t)p->width * p->height;
+    if (pixel_begin > npix || pixel_count > npix - pixel_begin) return fail(APT_ERR_ARG, "pixel range beyond the image%s");
+    if (pixel_count == 0) return APT_OK;
+    LeafProg lp;
+    if ((rc = make_leaf_prog(p->samples, lp))) return rc;
+    const int group = p->samples >= 8 ? 8 : 1;
+    const uint64_t lanes = pixel_count * 4u * (uint64_t)group;
+    const uint64_t blocks = (lanes + kBlock - 1) / kBlock;
+    if (blocks > 0x7fffffffull) return fail(APT_ERR_ARG, "pixel_count too large for one launch; shard it%s");
+    hipStream_t st = (hipStream_t)stream;
+    const bool ns8 = p->num_spheres == 8;
+    const TraceArgs ta = make_trace_args(p);
+    FrameArgs fa;
+    camera_init(fa.cam, p->width, p->height);
+    fa.width = p->width; fa.height = p->height; fa.samples = p->samples; fa.seed = p->seed;
+    fa.pixel_begin = pixel_begin; fa.pixel_count = pixel_count; fa.fb = fb; fa.fb_u8 = fb_u8;
+    const bool retire = p->flags & APT_FLAG_RETIRE;
+    const size_t lds = lp.nleaves > 1 ? (size_t)kMaxStack * 3 * kBlock * sizeof(float) : 0;
+    const dim3 grid((unsigned)blocks);
+    if (p->mode == APT_MODE_ORACLE) {
+        if (ns8) launch_frame_g<kModeOracle, true>(group, retire, grid, lds, st, spheres, fa, ta, lp);
+        else launch_frame_g<kModeOracle, false>(group, retire, grid, lds, st, spheres, fa, ta, lp);
+    } else {
+        if (ns8) launch_frame_g<kModeKernel, true>(group, retire, grid, lds, st, spheres, fa, ta, lp);
+        else launch_frame_g<kModeKernel, false>(group, retire, grid, lds, st, spheres, fa, ta, lp);
+    }
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? APT_OK : hip_fail(e);
+}
+
+int apt_gen_rays_device(const apt_render_params *p, void *stream, float *rays) {
+    int rc = check_params(p);
+    if (rc) return rc;
+    if (!rays) return fail(APT_ERR_ARG, "rays must be non-null%s");
+    const uint64_t n = (uint64_t)p->width * p->height * 4u * p->samples;
+    const uint64_t b = p->path_begin;
+    if (b > n) return fail(APT_ERR_ARG, "path_begin beyond the image%s");
+    const uint64_t c = p->path_count ? p->path_count : n - b;
+    if (b + c > n) return fail(APT_ERR_ARG, "path range beyond the image%s");
+    if (c == 0) return APT_OK;
+    const uint64_t blocks = (c + kBlock - 1) / kBlock;
+    if (blocks > 0x7fffffffull) return fail(APT_ERR_ARG, "path_count too large for one launch; shard it%s");
+    Camera cam;
+    camera_init(cam, p->width, p->height);
+    hipLaunchKernelGGL(gen_rays_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, cam, p->width,
+                       p->height, p->samples, p->seed, n, b, c, rays);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? APT_OK : hip_fail(e);
+}
+
+int apt_decode_color_device(const apt_render_params *p, void *stream, const float *colors, float *fb, uint8_t *fb_u8) {
+    int rc = check_params(p);
+    if (rc) return rc;
+    if (!colors || !fb) return fail(APT_ERR_ARG, "colors/fb must be non-null%s");
+    LeafProg lp;
+    if ((rc = make_leaf_prog(p->samples, lp))) return rc;
+    const uint64_t npix = (uint64_t)p->width * p->height;
+    const uint64_t lanes = npix * 3 * 4;
+    const uint64_t blocks = (lanes + kBlock - 1) / kBlock;
+    if (blocks > 0x7fffffffull) return fail(APT_ERR_ARG, "image too large for one launch%s");
+    hipLaunchKernelGGL(decode_color_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, colors,
+                       p->samples, npix, lp, fb, fb_u8);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? APT_OK : hip_fail(e);
+}
+
+} // extern "C"

@@ -1,0 +1,121 @@
+"""The render boundary, mirroring the reference host interface (src/main.cpp:9-10,74;
+src/render.cpp:262-266) on top of the C-ABI.  Tensors are torch CUDA(HIP) tensors used only
+as device buffers; the stream is a torch stream (or None = torch's current stream)."""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import RenderParams, check, lib, require_gpu
+
+
+def _stream_handle(stream):
+    if stream is None:
+        stream = torch.cuda.current_stream()
+    if isinstance(stream, int):
+        return ctypes.c_void_p(stream)
+    return ctypes.c_void_p(stream.cuda_stream)
+
+
+def _dev_f32(t, name, numel=None):
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+        raise _lib.AptError(f"{name} must be a contiguous float32 tensor on the GPU")
+    if numel is not None and t.numel() != numel:
+        raise _lib.AptError(f"{name} has {t.numel()} elements, expected {numel}")
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def sphere_floats(num_spheres):
+    """Length of the zero-padded [10][Ns] table (512-byte multiple, gen_data.py:120-127)."""
+    return (num_spheres * 10 + 127) // 128 * 128
+
+
+def render_do(blockDim, l2ctrl, stream, rays, spheres, colors):
+    """void render_do(blockDim, l2ctrl, stream, rays, spheres, colors) -- src/main.cpp:9-10,74.
+    Asynchronous on `stream`; uses the process-wide defaults (apt_set_default_params)."""
+    require_gpu()
+    lib().render_do(ctypes.c_uint32(blockDim), None, _stream_handle(stream), _dev_f32(rays, "rays"),
+                    _dev_f32(spheres, "spheres"), _dev_f32(colors, "colors"))
+    err = lib().apt_last_error()
+    if err:
+        raise _lib.AptError("render_do: " + err.decode())
+
+
+def set_default_params(params):
+    check(lib().apt_set_default_params(ctypes.byref(params)), "apt_set_default_params")
+
+
+def render_do_ex(params: RenderParams, stream, rays, spheres, colors):
+    """Run-time-parameter form of render_do: rays [6][N], spheres [10][Ns] padded, colors [3][N]."""
+    require_gpu()
+    n = params.num_paths
+    check(lib().render_do_ex(ctypes.byref(params), _stream_handle(stream), _dev_f32(rays, "rays", 6 * n),
+                             _dev_f32(spheres, "spheres", sphere_floats(params.num_spheres)),
+                             _dev_f32(colors, "colors", 3 * n)), "render_do_ex")
+
+
+def render_paths(params: RenderParams, rays, spheres, stream=None):
+    """Convenience: allocate colours, launch, return the [3][N] tensor (not synchronised)."""
+    colors = torch.empty(3 * params.num_paths, dtype=torch.float32, device=rays.device)
+    render_do_ex(params, stream, rays, spheres, colors)
+    return colors.view(3, -1)
+
+
+def render_frame(params: RenderParams, spheres, pixel_begin=0, pixel_count=None, stream=None, fb=None, fb_u8=None):
+    """Fused ray-generate + trace + decode for pixels [pixel_begin, pixel_begin+pixel_count).
+    Returns (fb float32 [3][count], fb_u8 uint8 [count][3]); not synchronised."""
+    require_gpu()
+    npix = params.width * params.height
+    if pixel_count is None:
+        pixel_count = npix - pixel_begin
+    if fb is None:
+        fb = torch.empty((3, pixel_count), dtype=torch.float32, device=spheres.device)
+    if fb_u8 is None:
+        fb_u8 = torch.empty((pixel_count, 3), dtype=torch.uint8, device=spheres.device)
+    check(lib().render_frame(ctypes.byref(params), _stream_handle(stream),
+                             _dev_f32(spheres, "spheres", sphere_floats(params.num_spheres)),
+                             ctypes.c_uint64(pixel_begin), ctypes.c_uint64(pixel_count), _dev_f32(fb, "fb", 3 * pixel_count),
+                             ctypes.c_void_p(fb_u8.data_ptr())), "render_frame")
+    return fb, fb_u8
+
+
+def gen_rays_device(params: RenderParams, stream=None, device="cuda"):
+    """Device gen_rays with the counter-based generator -> [6][N] tensor."""
+    require_gpu()
+    rays = torch.empty(6 * params.num_paths, dtype=torch.float32, device=device)
+    check(lib().apt_gen_rays_device(ctypes.byref(params), _stream_handle(stream), _dev_f32(rays, "rays")),
+          "apt_gen_rays_device")
+    return rays.view(6, -1)
+
+
+def decode_color_device(params: RenderParams, colors, stream=None):
+    """Device decode_color: colours [3][N] -> (fb float32 [3][W*H], fb_u8 [W*H][3])."""
+    require_gpu()
+    npix = params.width * params.height
+    fb = torch.empty((3, npix), dtype=torch.float32, device=colors.device)
+    u8 = torch.empty((npix, 3), dtype=torch.uint8, device=colors.device)
+    check(lib().apt_decode_color_device(ctypes.byref(params), _stream_handle(stream),
+                                        _dev_f32(colors.reshape(-1), "colors", 3 * params.num_paths),
+                                        ctypes.c_void_p(fb.data_ptr()), ctypes.c_void_p(u8.data_ptr())),
+          "apt_decode_color_device")
+    return fb, u8
+
+
+class TraceCounter:
+    """Optional device counter of traced ray segments (for reporting under APT_FLAG_RETIRE)."""
+
+    def __init__(self, device="cuda"):
+        self.buf = torch.zeros(1, dtype=torch.int64, device=device)
+
+    def __enter__(self):
+        self.buf.zero_()
+        lib().apt_set_trace_counter(ctypes.c_void_p(self.buf.data_ptr()))
+        return self
+
+    def __exit__(self, *exc):
+        torch.cuda.synchronize()
+        lib().apt_set_trace_counter(None)
+
+    @property
+    def value(self):
+        return int(self.buf.item())

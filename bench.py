@@ -1,0 +1,169 @@
+#!/usr/bin/env python3
+"""bench.py -- the reference's headline metric on MI355X: Mray/s on the demo scene at
+1920x1080, 8 bounces, 256 spp (BASELINE.json configs[1], "C2").
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one full frame through the hot path on every rank: rays generated on the
+device, all N*D ray segments traced, 4*S samples per pixel accumulated on the device, and
+(N > 1) the framebuffer slices gathered to rank 0 over RCCL.  Nothing is retired or
+skipped in the timed kernel (APT_FLAG_RETIRE off): every one of the W*H*4*S*D segments is
+traced, like the reference does.  Inputs (the 512-byte scene) are resident in HBM before
+the timed region.  Weak scaling: each rank owns a 1920-column band of a (1920*N)x1080 image.
+
+The JSON line carries `roofline` (fp32 VALU bound: SURVEY.md 8(d), F(Ns)=20*Ns+33 fp32
+operations per segment) and, at N=1 on rank 0, `cpu_baseline` (the oracle's C restatement
+timed on the host cores on a bounded pixel sample of the same workload).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+W, H, S, D, NS = 1920, 1080, 64, 8, 8
+PEAK_FP32_TFLOPS = 157.3                      # MI355X_MICROARCH.md: vector fp32 (== f32 MFMA) peak, FMA counted as 2
+PEAK_NOFMA_TOPS = 78.6                        # same lanes with FMA forbidden by bit-parity
+
+
+def flops_per_segment(ns):
+    return 20 * ns + 33                       # add/sub/mul/div/sqrt = 1 each
+
+
+def cpu_baseline(budget_s=12.0):
+    """The oracle (kind "port": the reference's own CPU path needs Huawei CANN and cannot be
+    built) on all host threads, on as many 4096-pixel chunks of the C2 frame as fit in
+    ~budget_s seconds.  Checker code: imported here only to be TIMED as the baseline."""
+    from oracle import oracle
+    threads = min(oracle.max_threads(), os.cpu_count() or 1)
+    sph = oracle.gen_spheres()
+    p = oracle.make_params(W, H, S, depth=D, num_spheres=NS, mode=oracle.MODE_K, seed=0)
+    chunk, done, seg = 4096, 0, 0
+    npix = W * H
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < budget_s and done < npix:
+        cnt = min(chunk, npix - done)
+        _, _, _, traced = oracle.render_frame(p, sph, pixel_begin=(done * 2654435761) % (npix - cnt + 1),
+                                              pixel_count=cnt, threads=threads)
+        seg += traced
+        done += cnt
+    dt = time.perf_counter() - t0
+    return {"value": round(seg / dt / 1e6, 3), "unit": "Mray/s", "cores": threads, "kind": "port",
+            "sample": f"{done} pixels of the {W}x{H} frame x {4 * S} spp x {D} bounces = {seg} segments in {dt:.1f} s "
+                      f"(K-mode C restatement, gcc -O2 -ffp-contract=off, OpenMP)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--retire", action="store_true", help="also time the frame with APT_FLAG_RETIRE (extra field)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import ascendpathtracing_amd as apt
+    from ascendpathtracing_amd import gen_data, render
+    from ascendpathtracing_amd import dist as apt_dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus} "
+                         f"(WORLD_SIZE is {world})")
+    apt._lib.require_gpu()
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    # weak scaling: the image grows by one 1920-column band per rank (x-major pixel index, so a
+    # band of columns is a contiguous pixel range: SURVEY.md 8(e))
+    width = W * world
+    p = apt.make_params(width, H, S, depth=D, num_spheres=NS, mode=apt.APT_MODE_KERNEL, seed=0)
+    sph = torch.from_numpy(gen_data.gen_spheres()).cuda()
+    shard = apt_dist.FrameShard(p, rank, world)
+    fb, u8 = shard.alloc()
+    full = shard.alloc_full() if rank == 0 else (None, None)
+
+    def step():
+        render.render_frame(p, sph, shard.pixel_begin, shard.pixel_count, fb=fb, fb_u8=u8)
+        if world > 1:
+            shard.gather(fb, u8, *full)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for a, b in ev:
+        a.record()                            # torch's current stream == the stream the kernel is launched on
+        render.render_frame(p, sph, shard.pixel_begin, shard.pixel_count, fb=fb, fb_u8=u8)
+        b.record()
+        if world > 1:
+            shard.gather(fb, u8, *full)
+    sync()
+    dt = time.perf_counter() - t0
+    kern_ms = sum(a.elapsed_time(b) for a, b in ev) / len(ev)     # HIP events around each launch
+
+    if world > 1:
+        t = torch.tensor([dt, kern_ms], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt, kern_ms = float(t[0]), float(t[1])
+
+    seg_per_rank = shard.pixel_count * 4 * S * D
+    seg_total = seg_per_rank * world
+    ms_per_step = dt / args.steps * 1e3
+    value = seg_total / (dt / args.steps) / 1e6
+    achieved = seg_per_rank * flops_per_segment(NS) / (kern_ms * 1e-3) / 1e12
+    out = {
+        "metric": "Mray/s (ray segments per second) at 1080p, 8 bounces, 256 spp, demo scene",
+        "value": round(value, 1), "unit": "Mray/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"C2: gen_spheres() 8-sphere scene, {W}x{H} per GPU ({width}x{H} total), "
+                               f"S={S} (256 spp), depth {D}, rays generated on device (counter RNG, seed 0), "
+                               f"K-mode arithmetic, all segments traced (no retirement)",
+                   "paths_per_gpu": shard.pixel_count * 4 * S, "segments_per_gpu": seg_per_rank,
+                   "parallelism": f"pixel-column bands x{world}, one RCCL gather" if world > 1 else "single GPU"},
+        "roofline": {"bound": "valu", "kernel": "render_frame_kernel<K,ns8,group8>", "achieved": round(achieved, 3),
+                     "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_TFLOPS, 4),
+                     "frac_of_nofma_peak": round(achieved / PEAK_NOFMA_TOPS, 4),
+                     "flops_per_segment": flops_per_segment(NS), "kernel_ms": round(kern_ms, 3),
+                     "traffic": apt_dist.recorded_traffic(ROOT)},
+        "target_mray_per_gpu": 100.0,
+    }
+    if args.retire:
+        pr = p.copy(flags=apt.APT_FLAG_RETIRE)
+        for _ in range(2):
+            render.render_frame(pr, sph, shard.pixel_begin, shard.pixel_count, fb=fb, fb_u8=u8)
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        with render.TraceCounter() as tc:
+            a.record()
+            render.render_frame(pr, sph, shard.pixel_begin, shard.pixel_count, fb=fb, fb_u8=u8)
+            b.record()
+        out["retire"] = {"kernel_ms": round(a.elapsed_time(b), 3), "traced_segments": tc.value,
+                         "nominal_segments": seg_per_rank}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -150,6 +150,11 @@ int apt_gen_scene_host(uint32_t num_spheres, uint64_t seed, float *spheres,
 int apt_write_ppm(const char *path, uint32_t width, uint32_t height, const uint8_t *fb_u8);
 
 /* ---- diagnostics ------------------------------------------------------------------- */
+/* Optional DEVICE uint64 counter to which every render launch adds the number of ray
+ * segments it actually traced (== paths*depth unless APT_FLAG_RETIRE).  NULL disables it.
+ * The caller zeroes it; process-wide. */
+int apt_set_trace_counter(uint64_t *device_counter);
+
 int         apt_abi_version(void);
 const char *apt_last_error(void);       /* thread-local, "" when none */
 int         apt_device_count(void);     /* number of HIP devices, 0 when none */

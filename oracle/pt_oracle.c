@@ -75,6 +75,8 @@ static uint32_t trace_path(const oracle_params *P, const float *sph, float ox, f
         for (uint32_t k = 0; k < Ns; ++k) {
             /* SphereHitInfo rt_helper.h:263-268: -(o + (-c)) == c - o exactly */
             float ocx = cx[k] - ox, ocy = cy[k] - oy, ocz = cz[k] - oz;
+            /* :273,:297 Duplicate(0) start omitted: exact except for the sign of a zero that
+             * cannot reach t (b only enters through b*b and b -/+ q); sim_npu omits it too. */
             float b = ocx * dx;            /* :278-280 FakeMulAddDst: mul, then add */
             b = b + ocy * dy;
             b = b + ocz * dz;
@@ -106,7 +108,7 @@ static uint32_t trace_path(const oracle_params *P, const float *sph, float ox, f
             acc += (double)(nx * nx); acc += (double)(ny * ny); acc += (double)(nz * nz);
             L = sqrtf((float)acc);
         } else {
-            float s = nx * nx; s = s + ny * ny; s = s + nz * nz;             /* :647-649 */
+            float s = 0.0f + nx * nx; s = s + ny * ny; s = s + nz * nz;      /* :641 Duplicate(0), :647-649 */
             L = sqrtf(s);                                                    /* :658 */
         }
         float ux = nx / L, uy = ny / L, uz = nz / L;                         /* :664-666 */
@@ -115,7 +117,7 @@ static uint32_t trace_path(const oracle_params *P, const float *sph, float ox, f
             acc += (double)(dx * ux); acc += (double)(dy * uy); acc += (double)(dz * uz);
             dot = (float)acc;
         } else {
-            dot = dx * ux; dot = dot + dy * uy; dot = dot + dz * uz;         /* :694-696 */
+            dot = 0.0f + dx * ux; dot = dot + dy * uy; dot = dot + dz * uz;  /* :690 Duplicate(0), :694-696 */
         }
         float k2 = dot * 2.0f;                                               /* :697 */
         dx = dx - ux * k2; dy = dy - uy * k2; dz = dz - uz * k2;             /* :699-703 */

@@ -1,0 +1,104 @@
+"""CPU-only: the C-ABI library loads and exports every symbol include/render_mi355x.h
+declares; the host-side helpers (no GPU needed) reproduce the reference's input files; the
+compute entry points refuse to run without a GPU instead of falling back."""
+import ctypes
+import hashlib
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def apt():
+    import __graft_entry__ as g
+    g.build()
+    import ascendpathtracing_amd as pkg
+    from ascendpathtracing_amd import gen_data
+    pkg.gen_data = gen_data
+    return pkg
+
+
+def test_every_declared_symbol_is_exported(apt):
+    hdr = open(os.path.join(ROOT, "include", "render_mi355x.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(render_do(?:_ex)?|render_frame|apt_[a-z0-9_]+)\s*\(", hdr))
+    declared.discard("apt_render_params")
+    assert {"render_do", "render_do_ex", "render_frame", "apt_gen_rays_host", "apt_write_ppm"} <= declared
+    h = ctypes.CDLL(apt._lib.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(h, name), f"{name} declared in include/render_mi355x.h but not exported"
+    assert set(apt._lib.ABI_SYMBOLS) == declared
+    assert h.apt_abi_version() == 1
+
+
+def test_params_struct_layout_matches_header(apt):
+    p = apt.default_params()
+    assert ctypes.sizeof(apt.RenderParams) == 72 == p.struct_size
+    # the reference's compile-time constants: common.h:4-10, render.cpp:141,194
+    assert (p.width, p.height, p.samples, p.depth, p.num_spheres, p.light_index) == (16, 16, 1, 5, 8, 7)
+    assert np.float32(p.eps) == np.float32(1e-4) and p.gain == 12.0 and p.mode == apt.APT_MODE_KERNEL and p.flags == 0
+
+
+def test_host_gen_rays_and_spheres_are_the_reference_files(apt, golden):
+    data, meta = golden
+    for key, (w, h, s) in {"16x16_s1": (16, 16, 1), "16x16_s2": (16, 16, 2), "24x16_s1": (24, 16, 1),
+                           "64x64_s1": (64, 64, 1)}.items():
+        rays = apt.gen_data.gen_rays(w, h, s, seed=0)
+        assert hashlib.sha256(rays.tobytes()).hexdigest() == meta["cases"][key]["rays_sha256"]
+        assert np.array_equal(rays.ravel().view(np.uint32), data[f"{key}_rays"].view(np.uint32))
+    sph = apt.gen_data.gen_spheres()
+    assert hashlib.sha256(sph.tobytes()).hexdigest() == meta["cases"]["16x16_s1"]["spheres_sha256"]
+
+
+def test_file_contract_of_gen_data(apt, tmp_path, golden):
+    _, meta = golden
+    apt.gen_data.gen_rays(16, 16, 1, seed=0, out_dir=str(tmp_path))
+    apt.gen_data.gen_spheres(out_dir=str(tmp_path))
+    assert os.path.getsize(tmp_path / "rays.bin") == 16 * 16 * 4 * 6 * 4       # main.cpp:47
+    assert os.path.getsize(tmp_path / "spheres.bin") == 512                    # main.cpp:48
+    assert hashlib.sha256((tmp_path / "rays.bin").read_bytes()).hexdigest() == meta["cases"]["16x16_s1"]["rays_sha256"]
+
+
+def test_scene_generator_matches_restatement_and_keeps_walls_and_light(apt, oracle):
+    for ns in (8, 9, 100, 10000):
+        a, b = apt.gen_data.gen_scene(ns, seed=42), oracle.gen_scene(ns, seed=42)
+        assert a.size % 128 == 0 and np.array_equal(a.view(np.uint32), b.view(np.uint32))
+        tab = a[:10 * ns].reshape(10, ns)
+        ref = apt.gen_data.gen_spheres()[:80].reshape(10, 8)
+        assert np.array_equal(tab[:, :6], ref[:, :6]) and np.array_equal(tab[:, ns - 1], ref[:, 7])
+        if ns > 8:
+            mid = tab[:, 6:ns - 1]
+            assert (mid[0] >= 0.25).all() and (mid[0] <= 4.0).all() and (mid[7:10] >= 0.1).all()
+    with pytest.raises(apt.AptError):
+        apt.gen_data.gen_scene(7)
+
+
+def test_write_ppm_matches_reference_bytes(apt, golden, tmp_path):
+    from ascendpathtracing_amd import data_visualization as dv
+    data, meta = golden
+    for name, m in meta["decode"].items():
+        w, h = m["w"], m["h"]
+        u8 = data[f"decode_{name}_u8"][:, ::-1, :].reshape(-1, 3)    # undo the y flip -> x-major pixels
+        out = tmp_path / f"{name}.ppm"
+        dv.write_ppm(w, h, u8, str(out))
+        assert out.read_bytes() == data[f"decode_{name}_ppm"].tobytes()
+    dv.write_ppm(3, 2, np.arange(18, dtype=np.uint8), str(tmp_path / "ns.ppm"))   # non-square: h rows of w pixels
+    lines = (tmp_path / "ns.ppm").read_text().splitlines()
+    assert lines[:3] == ["P3", "3 2", "255"] and len(lines) == 5
+    assert lines[3].split() == ["3", "4", "5", "9", "10", "11", "15", "16", "17"]   # top row = y 1
+
+
+def test_compute_entries_fail_loudly_without_a_gpu(apt):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from ascendpathtracing_amd import render
+    with pytest.raises(apt.AptError, match="no HIP device"):
+        render.render_frame(apt.make_params(), torch.zeros(128))
+    with pytest.raises(apt.AptError, match="no HIP device"):
+        render.render_do(8, None, 0, torch.zeros(6), torch.zeros(128), torch.zeros(3))
+    assert apt._lib.lib().apt_device_count() == 0
