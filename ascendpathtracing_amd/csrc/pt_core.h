@@ -76,17 +76,128 @@ APT_HD float intersect_post(HitPre h, float eps) {
     return (t > eps) ? t : kMissT;
 }
 
+#if defined(__HIP_DEVICE_COMPILE__)
+// Correctly rounded sqrt for the device hot loop.  hipcc's sqrtf() is v_sqrt_f32 (<= 1 ulp)
+// followed by a check of the two neighbouring floats with exact FMA residuals, wrapped in a
+// 2^32 pre-scale for inputs below 2^-96 and a class test for 0/inf.  The wrapper is 7 of its
+// 16 instructions and is only needed for |x| < 2^-96 (v_sqrt_f32 does not take denormals), so
+// the hot loop runs the core alone and reports such inputs through `tiny`; the caller then
+// redoes the bounce with sqrtf() (wave-uniform branch, practically never taken; `amin` is the
+// running minimum of |x| over the bounce, one v_min_f32 per call).  NaN, +inf
+// and negative inputs come out as sqrtf() gives them (NaN compares false in both selects).
+// tests/test_gpu_parity.py::test_fast_sqrt_exhaustive checks all 2^32 bit patterns.
+__device__ __forceinline__ float sqrt_rn_core(float x, float &amin) {
+    amin = fminf(amin, fabsf(x)); // caller tests amin < 2^-96 once per bounce
+    float y = __builtin_amdgcn_sqrtf(x);
+    const float yd = __int_as_float(__float_as_int(y) - 1);
+    const float yu = __int_as_float(__float_as_int(y) + 1);
+    const float rd = __builtin_fmaf(-yd, y, x); // x - yd*y, exact sign
+    const float ru = __builtin_fmaf(-yu, y, x);
+    y = (rd <= 0.0f) ? yd : y;
+    y = (ru > 0.0f) ? yu : y;
+    return y;
+}
+// Candidate: Markstein-style correction.  y0 = v_sqrt_f32(x) is within 1 ulp, so the residual
+// x - y0*y0 is exactly representable and one FMA with h ~ 1/(2*sqrt(x)) lands on the correctly
+// rounded result (sqrt has no exact halfway cases).  5 instructions, no compare/select.
+// Verified exhaustively against sqrtf() by the same self-test before it may be used.
+__device__ __forceinline__ float sqrt_rn_markstein(float x, float &amin) {
+    amin = fminf(amin, fabsf(x));
+    const float y = __builtin_amdgcn_sqrtf(x);
+    const float h = 0.5f * __builtin_amdgcn_rsqf(x);
+    const float r = __builtin_fmaf(-y, y, x);
+    return __builtin_fmaf(r, h, y);
+}
+
+#endif
+
+// The two roots b -/+ q of one ray/sphere pair; FAST uses sqrt_rn_markstein on the device.
+// sqrt_rn_markstein differs from sqrtf() for exactly one input, +inf (NaN instead of +inf); an
+// infinite discriminant makes t = +inf with sqrtf() and kMissT with the NaN, and neither can win
+// the strict '<' arg-min against tmin <= kMissT, so the selected sphere and tmin are unchanged.
+template <bool FAST>
+APT_HD void intersect_roots(float cx, float cy, float cz, float r2, float ox, float oy, float oz, float dx, float dy,
+                            float dz, float &t0, float &t1, float &amin) {
+    float ocx = cx - ox, ocy = cy - oy, ocz = cz - oz;
+    float b = ocx * dx;
+    b = b + ocy * dy;
+    b = b + ocz * dz;
+    float c = ocx * ocx;
+    c = c + ocy * ocy;
+    c = c + ocz * ocz;
+    c = c - r2;
+    float disc = b * b;
+    disc = disc - c;
+    float q;
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (FAST) q = sqrt_rn_markstein(disc, amin);
+    else
+#endif
+        q = sqrtf(disc);
+    (void)amin;
+    t0 = b - q;
+    t1 = b + q;
+}
+
+// Root selection of rt_helper.h:341-363 as the reference writes it.
+APT_HD float select_root(float t0, float t1, float eps) {
+    float t = (t0 > eps) ? t0 : t1;
+    return (t > eps) ? t : kMissT;
+}
+
+// The same selection and the running arg-min in the integer domain, valid for 0 < eps < kMissT.
+// For a float x with bit pattern u(x): x is an acceptable root (eps < x, not NaN) exactly when
+// key(x) = u(x) - (u(eps)+1), as an unsigned number, is <= u(+inf) - (u(eps)+1); keys of
+// acceptable roots are ordered like the roots; negative numbers, zeros, values <= eps and NaNs of
+// either sign wrap to keys above every acceptable one.  Since t1 >= t0 whenever both are numbers,
+// "t0 if t0 > eps else t1 if t1 > eps else miss" is min(key(t0), key(t1)), and a root beats the
+// running minimum (initially kMissT) exactly when its key is below the running key (initially
+// key(kMissT)), so tmin = value(running key) needs no select at the end.
+struct RootKey {
+    uint32_t bias;  // u(eps) + 1
+    uint32_t best;  // running minimum key, starts at key(kMissT)
+    int idx;        // sphere of the running minimum (lowest index on ties: strict '<')
+};
+APT_HD uint32_t f32_bits(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __float_as_uint(x);
+#else
+    union { float f; uint32_t u; } v; v.f = x; return v.u;
+#endif
+}
+APT_HD float bits_f32(uint32_t u) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __uint_as_float(u);
+#else
+    union { float f; uint32_t u; } v; v.u = u; return v.f;
+#endif
+}
+APT_HD void rootkey_init(RootKey &k, float eps, int miss_idx) {
+    k.bias = f32_bits(eps) + 1u;
+    k.best = f32_bits(kMissT) - k.bias;
+    k.idx = miss_idx;
+}
+APT_HD void rootkey_update(RootKey &k, float t0, float t1, int sphere) {
+    const uint32_t m0 = f32_bits(t0) - k.bias, m1 = f32_bits(t1) - k.bias;
+    const uint32_t m = m0 < m1 ? m0 : m1;
+    const uint32_t nb = m < k.best ? m : k.best;
+    k.idx = (nb != k.best) ? sphere : k.idx;
+    k.best = nb;
+}
+APT_HD float rootkey_tmin(const RootKey &k) { return bits_f32(k.best + k.bias); }
+APT_HD bool eps_allows_rootkey(float eps) { return eps > 0.0f && eps < kMissT; }
+
 // State of one path between bounces.
 struct PathState {
     float ox, oy, oz, dx, dy, dz; // ray (updated in place, rt_helper.h:699-708)
     float rx, ry, rz;             // throughput `ret` (render.cpp:116-121)
-    bool alive;                   // retMask bit (render.cpp:123-124)
+    uint32_t alive;               // retMask bit (render.cpp:123-124); a dword so the struct has no padding
 };
 
 APT_HD void path_init(PathState &s, float ox, float oy, float oz, float dx, float dy, float dz) {
     s.ox = ox; s.oy = oy; s.oz = oz; s.dx = dx; s.dy = dy; s.dz = dz;
     s.rx = 1.0f; s.ry = 1.0f; s.rz = 1.0f;
-    s.alive = true;
+    s.alive = 1u;
 }
 
 // A finished path: nothing a further bounce does can change its colour (Appendix A notes).
@@ -96,9 +207,9 @@ APT_HD bool path_finished(const PathState &s) {
 
 // GenerateNewRays + AccumulateIntervalColor for the hit (tmin, sphere centre c, albedo col).
 // is_light: the arg-min index equals light_index.
-template <int MODE>
+template <int MODE, bool FAST = false>
 APT_HD void shade_and_reflect(PathState &s, float tmin, float cx, float cy, float cz, float colx, float coly,
-                              float colz, bool is_light) {
+                              float colz, bool is_light, float *amin = nullptr) {
     float hx = s.dx * tmin, hy = s.dy * tmin, hz = s.dz * tmin; // rt_helper.h:513-518
     hx = s.ox + hx; hy = s.oy + hy; hz = s.oz + hz;
     float nx = hx - cx, ny = hy - cy, nz = hz - cz;             // :635-637
@@ -108,13 +219,18 @@ APT_HD void shade_and_reflect(PathState &s, float tmin, float cx, float cy, floa
         double acc = 0.0 + (double)p0;                          // sdot: double dot = 0.0; dot += y*x
         acc = acc + (double)p1;
         acc = acc + (double)p2;
-        L = sqrtf((float)acc);
+        L = (float)acc;
     } else {
         float acc = 0.0f + nx * nx;                             // :641 Duplicate(0), :647-649
         acc = acc + ny * ny;
         acc = acc + nz * nz;
-        L = sqrtf(acc);                                         // :658
+        L = acc;
     }
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (FAST) L = sqrt_rn_core(L, *amin);
+    else
+#endif
+        L = sqrtf(L);                                           // :658
     float ux = nx / L, uy = ny / L, uz = nz / L;                // :664-666 IEEE divide
     float dot;
     if (MODE == kModeOracle) {                                  // np.dot, gen_data.py:349
@@ -132,7 +248,7 @@ APT_HD void shade_and_reflect(PathState &s, float tmin, float cx, float cy, floa
     float mx = ux * k2, my = uy * k2, mz = uz * k2;             // :699-701
     s.dx = s.dx - mx; s.dy = s.dy - my; s.dz = s.dz - mz;       // :702-704
     s.ox = hx; s.oy = hy; s.oz = hz;                            // :706-708
-    s.alive = s.alive && !is_light;                             // :773-787
+    s.alive = (s.alive && !is_light) ? 1u : 0u;                 // :773-787
     if (s.alive) {                                              // :799-810 (x1 is exact otherwise)
         s.rx = colx * s.rx; s.ry = coly * s.ry; s.rz = colz * s.rz;
     }

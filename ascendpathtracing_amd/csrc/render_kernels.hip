@@ -59,31 +59,73 @@ struct TraceArgs {
 
 struct LeafProg { // numpy pairwise_sum recursion flattened (see build_leaves)
     uint32_t nleaves;
-    uint16_t len[kMaxLeaves];
-    uint8_t ncomb[kMaxLeaves];
+    uint32_t leaf[kMaxLeaves]; // len | ncomb << 16 (dwords: wave-uniform s_load from the kernarg segment)
+    __host__ __device__ uint32_t len(uint32_t i) const { return leaf[i] & 0xffffu; }
+    __host__ __device__ uint32_t ncomb(uint32_t i) const { return leaf[i] >> 16; }
 };
 
 // ---- trace: reference scene (Ns == 8) ----------------------------------------------------
+// One bounce: 8 intersections (sphere operands in SGPRs), arg-min, gather, shade.
+// FAST: exact fast sqrt sequences (pt_core.h) and, when eps permits, the integer-key arg-min.
+template <int MODE, bool FAST>
+__device__ __forceinline__ bool bounce_ns8(const Scene8 &sc, const float4 *tab, const PathState &s, PathState &n,
+                                           const TraceArgs &ta) {
+    float amin = 1.0f; // min |sqrt argument| of this bounce (FAST only)
+    float tmin;
+    int idx;
+    const int miss = (MODE == kModeOracle) ? -1 : 0; // all-miss: gen_data.py:311 / rt_helper.h:183-201
+    if (FAST) {
+        RootKey key;
+        rootkey_init(key, ta.eps, miss);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { // rt_helper.h:457-467
+            float t0, t1;
+            intersect_roots<true>(sc.cx[k], sc.cy[k], sc.cz[k], sc.r2[k], s.ox, s.oy, s.oz, s.dx, s.dy, s.dz, t0, t1,
+                                  amin);
+            rootkey_update(key, t0, t1, k);
+        }
+        tmin = rootkey_tmin(key);
+        idx = key.idx;
+    } else {
+        tmin = kMissT;
+        idx = miss;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            float t0, t1;
+            intersect_roots<false>(sc.cx[k], sc.cy[k], sc.cz[k], sc.r2[k], s.ox, s.oy, s.oz, s.dx, s.dy, s.dz, t0, t1,
+                                   amin);
+            const float t = select_root(t0, t1, ta.eps);
+            if (t < tmin) { tmin = t; idx = k; } // strict '<', ascending k: lowest index wins ties
+        }
+    }
+    const int g = (idx < 0) ? 7 : idx; // Python index -1 wraps to the last sphere
+    const float4 c = tab[2 * g], col = tab[2 * g + 1];
+    n = s;
+    shade_and_reflect<MODE, FAST>(n, tmin, c.x, c.y, c.z, col.x, col.y, col.z, idx == ta.light, &amin);
+    // the fast sequences are only valid for |sqrt argument| >= 2^-96 and 0 < eps < 1e20
+    return FAST && (amin < 0x1p-96f || !eps_allows_rootkey(ta.eps));
+}
+
 template <int MODE, bool RETIRE>
 __device__ __forceinline__ uint32_t trace_ns8(const Scene8 &sc, const float4 *tab, PathState &s, bool valid,
                                               const TraceArgs &ta) {
     uint32_t traced = 0;
     for (uint32_t d = 0; d < ta.depth; ++d) { // render.cpp:140-188
-        const bool fin = !valid || (RETIRE && path_finished(s));
+        const bool fin = RETIRE && (!valid || path_finished(s));
         if (RETIRE && __all(fin)) break;
-        float tmin = kMissT;
-        int idx = (MODE == kModeOracle) ? -1 : 0; // all-miss: gen_data.py:311 / rt_helper.h:183-201
-#pragma unroll
-        for (int k = 0; k < 8; ++k) { // rt_helper.h:457-467
-            const float t = intersect_sphere(sc.cx[k], sc.cy[k], sc.cz[k], sc.r2[k], s.ox, s.oy, s.oz, s.dx, s.dy,
-                                             s.dz, ta.eps);
-            if (t < tmin) { tmin = t; idx = k; } // strict '<', ascending k: lowest index wins ties
+        PathState n;
+        if (__builtin_expect(__any(bounce_ns8<MODE, true>(sc, tab, s, n, ta)), 0)) {
+            // some |sqrt argument| < 2^-96 in this wave: redo the bounce with sqrtf().  The empty
+            // volatile asm keeps the compiler from speculating this cold path into the hot block.
+            asm volatile("" ::: "memory");
+            (void)bounce_ns8<MODE, false>(sc, tab, s, n, ta);
         }
-        const int g = (idx < 0) ? 7 : idx; // Python index -1 wraps to the last sphere
-        const float4 c = tab[2 * g], col = tab[2 * g + 1];
-        PathState n = s;
-        shade_and_reflect<MODE>(n, tmin, c.x, c.y, c.z, col.x, col.y, col.z, idx == ta.light);
-        if (!fin) { s = n; ++traced; }
+        if (RETIRE) {
+            if (!fin) { s = n; ++traced; }
+        } else { // full trace: lanes past the end of the range compute garbage that is never stored
+            s = n;
+            ++traced;
+        }
     }
     return traced;
 }
@@ -224,7 +266,7 @@ __global__ __launch_bounds__(kBlock) void render_frame_kernel(const float *__res
     uint32_t start = 0;
     int sp = 0;
     for (uint32_t leaf = 0; leaf < lp.nleaves; ++leaf) {
-        const uint32_t n = lp.len[leaf];
+        const uint32_t n = lp.len(leaf);
         float acc[3], c[3];
         if (GROUP == 1) { // n < 8: res = 0; res += a[i]
             acc[0] = acc[1] = acc[2] = 0.0f;
@@ -263,7 +305,7 @@ __global__ __launch_bounds__(kBlock) void render_frame_kernel(const float *__res
 #pragma unroll
             for (int ch = 0; ch < 3; ++ch) stack_lds[(sp * 3 + ch) * kBlock + threadIdx.x] = acc[ch];
             ++sp;
-            for (uint32_t m = 0; m < lp.ncomb[leaf]; ++m) {
+            for (uint32_t m = 0; m < lp.ncomb(leaf); ++m) {
                 --sp;
 #pragma unroll
                 for (int ch = 0; ch < 3; ++ch) {
@@ -350,9 +392,9 @@ __global__ __launch_bounds__(kBlock) void decode_color_kernel(const float *__res
     int sp = 0;
     uint32_t start = 0;
     for (uint32_t leaf = 0; leaf < lp.nleaves; ++leaf) {
-        st[sp++] = pairwise_leaf(a + start, lp.len[leaf]);
-        start += lp.len[leaf];
-        for (uint32_t m = 0; m < lp.ncomb[leaf]; ++m) { --sp; st[sp - 1] = st[sp - 1] + st[sp]; }
+        st[sp++] = pairwise_leaf(a + start, lp.len(leaf));
+        start += lp.len(leaf);
+        for (uint32_t m = 0; m < lp.ncomb(leaf); ++m) { --sp; st[sp - 1] = st[sp - 1] + st[sp]; }
     }
     const float mean = st[0] / (float)samples;
     const int gbase = (int)((threadIdx.x & 63) & ~3u);
@@ -365,6 +407,32 @@ __global__ __launch_bounds__(kBlock) void decode_color_kernel(const float *__res
         fb[ch * npix + q] = (float)cl;
         if (fb_u8) fb_u8[q * 3 + ch] = (uint8_t)(cl * 255);
     }
+}
+
+// ---- kernel: exhaustive self-test of the fast correctly-rounded sqrt ------------------------
+// Every float bit pattern in [begin, begin+count): variant(x) must equal sqrtf(x) bit for bit
+// (any NaN == any NaN) unless the variant asks for the fallback (|x| < 2^-96), in which case the
+// hot loop would have used sqrtf() anyway.  Counts mismatches; remembers the first one.
+__global__ __launch_bounds__(kBlock) void selftest_sqrt_kernel(int variant, uint64_t begin, uint64_t count,
+                                                               unsigned long long *result) {
+#if defined(__HIP_DEVICE_COMPILE__) // the sqrt variants are device-only builtins
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    unsigned long long bad = 0, first = ~0ull;
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < count; i += stride) {
+        const uint32_t bits = (uint32_t)(begin + i);
+        const float x = __uint_as_float(bits);
+        float amin = 1.0f;
+        const float got = variant == 0 ? sqrt_rn_core(x, amin) : sqrt_rn_markstein(x, amin);
+        const float want = sqrtf(x);
+        const bool fallback = amin < 0x1p-96f;
+        const bool same = (__float_as_uint(got) == __float_as_uint(want)) || (got != got && want != want);
+        if (!same && !fallback) { ++bad; if (first == ~0ull) first = bits; }
+    }
+    if (bad) {
+        atomicAdd(&result[0], bad);
+        atomicMin(&result[1], first);
+    }
+#endif
 }
 
 // ---- host side ----------------------------------------------------------------------------
@@ -395,7 +463,7 @@ int make_leaf_prog(uint32_t samples, LeafProg &lp) {
     if (v.size() > (size_t)kMaxLeaves) return fail(APT_ERR_ARG, "samples too large for the pairwise plan (max 8192)%s");
     memset(&lp, 0, sizeof lp);
     lp.nleaves = (uint32_t)v.size();
-    for (size_t i = 0; i < v.size(); ++i) { lp.len[i] = (uint16_t)v[i].first; lp.ncomb[i] = (uint8_t)v[i].second; }
+    for (size_t i = 0; i < v.size(); ++i) lp.leaf[i] = v[i].first | (v[i].second << 16);
     return APT_OK;
 }
 
@@ -470,6 +538,16 @@ int apt_set_default_params(const apt_render_params *p) {
     g_default = *p;
     g_default_init = true;
     return APT_OK;
+}
+
+int apt_selftest_sqrt(int variant, void *stream, uint64_t first_bits, uint64_t count, uint64_t *device_result2) {
+    if (!device_result2 || variant < 0 || variant > 1) return fail(APT_ERR_ARG, "apt_selftest_sqrt: bad arguments%s");
+    if (first_bits + count > (1ull << 32)) return fail(APT_ERR_ARG, "apt_selftest_sqrt: range beyond 2^32%s");
+    if (count == 0) return APT_OK;
+    hipLaunchKernelGGL(selftest_sqrt_kernel, dim3(256 * 16), dim3(kBlock), 0, (hipStream_t)stream, variant, first_bits,
+                       count, (unsigned long long *)device_result2);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? APT_OK : hip_fail(e);
 }
 
 int apt_set_trace_counter(uint64_t *device_counter) {

@@ -119,3 +119,14 @@ class TraceCounter:
     @property
     def value(self):
         return int(self.buf.item())
+
+
+def selftest_sqrt(variant=0, first_bits=0, count=1 << 32, stream=None):
+    """Exhaustive check of the hot loop's fast sqrt against sqrtf(): -> (mismatches, first bad bits)."""
+    require_gpu()
+    res = torch.tensor([0, -1], dtype=torch.int64, device="cuda")
+    check(lib().apt_selftest_sqrt(ctypes.c_int(variant), _stream_handle(stream), ctypes.c_uint64(first_bits),
+                                  ctypes.c_uint64(count), ctypes.c_void_p(res.data_ptr())), "apt_selftest_sqrt")
+    torch.cuda.synchronize()
+    bad, first = res.tolist()
+    return bad, first & 0xFFFFFFFF

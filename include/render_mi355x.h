@@ -155,6 +155,14 @@ int apt_write_ppm(const char *path, uint32_t width, uint32_t height, const uint8
  * The caller zeroes it; process-wide. */
 int apt_set_trace_counter(uint64_t *device_counter);
 
+/* Self-test of the hot loop's fast correctly-rounded sqrt: compares it with sqrtf() for every
+ * float whose bit pattern lies in [first_bits, first_bits+count) (count = 2^32 covers all).
+ * variant 0 = the sequence the kernels use, 1 = the Markstein candidate.
+ * device_result2[0] += number of mismatches, device_result2[1] = min(first mismatching bits);
+ * the caller initialises them to 0 and ~0. */
+int apt_selftest_sqrt(int variant, void *stream, uint64_t first_bits, uint64_t count,
+                      uint64_t *device_result2);
+
 int         apt_abi_version(void);
 const char *apt_last_error(void);       /* thread-local, "" when none */
 int         apt_device_count(void);     /* number of HIP devices, 0 when none */
