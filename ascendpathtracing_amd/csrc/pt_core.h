@@ -109,6 +109,27 @@ __device__ __forceinline__ float sqrt_rn_markstein(float x, float &amin) {
     return __builtin_fmaf(r, h, y);
 }
 
+// Candidates with ONE transcendental (v_rsq_f32 only), tried by the exhaustive self-test:
+//   2: one coupled step          y = x*r, h = r/2, y' = fma(fma(-y,y,x), h, y)
+//   3: hipcc's flush-mode lowering (two steps): e = fma(-h,y,.5); y=fma(y,e,y); h=fma(h,e,h); y'=fma(fma(-y,y,x),h,y)
+__device__ __forceinline__ float sqrt_rn_rsq1(float x, float &amin) {
+    amin = fminf(amin, fabsf(x));
+    const float r0 = __builtin_amdgcn_rsqf(x);
+    const float y = x * r0, h = 0.5f * r0;
+    const float r = __builtin_fmaf(-y, y, x);
+    return __builtin_fmaf(r, h, y);
+}
+__device__ __forceinline__ float sqrt_rn_rsq2(float x, float &amin) {
+    amin = fminf(amin, fabsf(x));
+    const float r0 = __builtin_amdgcn_rsqf(x);
+    float y = x * r0, h = 0.5f * r0;
+    const float e = __builtin_fmaf(-h, y, 0.5f);
+    y = __builtin_fmaf(y, e, y);
+    h = __builtin_fmaf(h, e, h);
+    const float r = __builtin_fmaf(-y, y, x);
+    return __builtin_fmaf(r, h, y);
+}
+
 #endif
 
 // The two roots b -/+ q of one ray/sphere pair; FAST uses sqrt_rn_markstein on the device.

@@ -422,7 +422,8 @@ __global__ __launch_bounds__(kBlock) void selftest_sqrt_kernel(int variant, uint
         const uint32_t bits = (uint32_t)(begin + i);
         const float x = __uint_as_float(bits);
         float amin = 1.0f;
-        const float got = variant == 0 ? sqrt_rn_core(x, amin) : sqrt_rn_markstein(x, amin);
+        const float got = variant == 0 ? sqrt_rn_core(x, amin) : variant == 1 ? sqrt_rn_markstein(x, amin)
+                        : variant == 2 ? sqrt_rn_rsq1(x, amin) : sqrt_rn_rsq2(x, amin);
         const float want = sqrtf(x);
         const bool fallback = amin < 0x1p-96f;
         const bool same = (__float_as_uint(got) == __float_as_uint(want)) || (got != got && want != want);
@@ -541,7 +542,7 @@ int apt_set_default_params(const apt_render_params *p) {
 }
 
 int apt_selftest_sqrt(int variant, void *stream, uint64_t first_bits, uint64_t count, uint64_t *device_result2) {
-    if (!device_result2 || variant < 0 || variant > 1) return fail(APT_ERR_ARG, "apt_selftest_sqrt: bad arguments%s");
+    if (!device_result2 || variant < 0 || variant > 3) return fail(APT_ERR_ARG, "apt_selftest_sqrt: bad arguments%s");
     if (first_bits + count > (1ull << 32)) return fail(APT_ERR_ARG, "apt_selftest_sqrt: range beyond 2^32%s");
     if (count == 0) return APT_OK;
     hipLaunchKernelGGL(selftest_sqrt_kernel, dim3(256 * 16), dim3(kBlock), 0, (hipStream_t)stream, variant, first_bits,

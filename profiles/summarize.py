@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""Condense a gpurun_out/prof_<tag>/ directory (written by profiles/run_profile.sh) into the
+committed evidence:  profiles/<tag>_kernel_stats.csv, profiles/<tag>_pmc.json and
+profiles/hbm_traffic.json (what bench.py reports as roofline.traffic).
+    python profiles/summarize.py <tag> [bench_json]"""
+import collections, csv, glob, json, os, shutil, sys
+
+tag = sys.argv[1]
+src = f"gpurun_out/prof_{tag}"
+here = os.path.dirname(os.path.abspath(__file__))
+stats = glob.glob(f"{src}/trace/*/*_kernel_stats.csv")[0]
+shutil.copy(stats, f"{here}/{tag}_kernel_stats.csv")
+rows = list(csv.DictReader(open(stats)))
+main = max(rows, key=lambda r: float(r["TotalDurationNs"]))
+pmc = {}
+for f in sorted(glob.glob(f"{src}/pmc*/*/*_counter_collection.csv")):
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        if r["Kernel_Name"] == main["Name"]:
+            agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+    for k, v in agg.items():
+        pmc[k] = {"launches": len(v), "avg": sum(v) / len(v)}
+out = {"tag": tag, "command": "python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline",
+       "kernel": main["Name"], "calls": int(main["Calls"]), "avg_ns": float(main["AverageNs"]),
+       "min_ns": float(main["MinNs"]), "max_ns": float(main["MaxNs"]), "pmc": pmc}
+if "GRBM_GUI_ACTIVE" in pmc:   # summed over the 8 XCDs (MI355X_MICROARCH.md, DVFS give-back)
+    out["effective_clock_ghz"] = pmc["GRBM_GUI_ACTIVE"]["avg"] / 8 / out["avg_ns"]
+if "SQ_INSTS_VALU" in pmc and "SQ_WAVES" in pmc:
+    out["valu_insts_per_wave"] = pmc["SQ_INSTS_VALU"]["avg"] / pmc["SQ_WAVES"]["avg"]
+    out["valu_insts_per_segment"] = out["valu_insts_per_wave"] / 64.0          # 8 samples x 8 bounces per lane
+    if "GRBM_GUI_ACTIVE" in pmc:
+        out["simd_cycles_per_valu_inst"] = pmc["GRBM_GUI_ACTIVE"]["avg"] / 8 * 1024 / pmc["SQ_INSTS_VALU"]["avg"]
+json.dump(out, open(f"{here}/{tag}_pmc.json", "w"), indent=1)
+if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
+    # rocprofv3 reports KiB; gfx950: FETCH_SIZE reads half of the bytes actually fetched (guide, HBM section)
+    fetch = pmc["FETCH_SIZE"]["avg"] * 1024 * 2
+    write = pmc["WRITE_SIZE"]["avg"] * 1024
+    json.dump({"tag": tag, "kernel": main["Name"], "fetch_bytes_per_launch_corrected_x2": fetch,
+               "write_bytes_per_launch": write, "hbm_bytes_per_launch": fetch + write,
+               "algorithmic_bytes_per_launch": 1920 * 1080 * 15 + 512,
+               "note": "separate --pmc FETCH_SIZE / --pmc WRITE_SIZE passes; FETCH_SIZE doubled per MI355X_MICROARCH.md"},
+              open(f"{here}/hbm_traffic.json", "w"), indent=1)
+if len(sys.argv) > 2:
+    shutil.copy(sys.argv[2], f"{here}/{tag}_bench.json")
+print(json.dumps(out, indent=1)[:1500])
