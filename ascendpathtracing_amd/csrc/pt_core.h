@@ -130,10 +130,35 @@ __device__ __forceinline__ float sqrt_rn_rsq2(float x, float &amin) {
     return __builtin_fmaf(r, h, y);
 }
 
+// Three correctly rounded quotients by one divisor.  hipcc lowers every fp32 `/` to
+//   v_div_scale x2, v_rcp, fma, fma (refine 1/d), mul, fma, fma, fma, v_div_fmas, v_div_fixup.
+// When neither operand needs scaling (no operand or quotient near the ends of the exponent
+// range, numerator non-zero) div_scale and div_fixup are identities and div_fmas is a plain FMA,
+// so the reciprocal refinement can be shared by the three numerators: 1 rcp + 2 + 3*5 ops instead
+// of 3*11.  `ok` is cleared when any |operand| is outside [2^-40, 2^40] (or NaN); the caller then
+// redoes the bounce with the plain `/`.  apt_selftest_div3 compares it with `/` on 2^32
+// structured + random operand sets.
+__device__ __forceinline__ void div3_shared(float nx, float ny, float nz, float d, float &ux, float &uy, float &uz,
+                                            bool &ok) {
+    const float lo = fminf(fminf(fabsf(nx), fabsf(ny)), fminf(fabsf(nz), fabsf(d)));
+    const float hi = fmaxf(fmaxf(fabsf(nx), fabsf(ny)), fmaxf(fabsf(nz), fabsf(d)));
+    ok = ok && (lo >= 0x1p-40f) && (hi <= 0x1p40f);
+    const float r0 = __builtin_amdgcn_rcpf(d);
+    const float e0 = __builtin_fmaf(-d, r0, 1.0f);
+    const float r = __builtin_fmaf(e0, r0, r0);
+    float q, e;
+    q = nx * r; e = __builtin_fmaf(-d, q, nx); q = __builtin_fmaf(e, r, q); e = __builtin_fmaf(-d, q, nx);
+    ux = __builtin_fmaf(e, r, q);
+    q = ny * r; e = __builtin_fmaf(-d, q, ny); q = __builtin_fmaf(e, r, q); e = __builtin_fmaf(-d, q, ny);
+    uy = __builtin_fmaf(e, r, q);
+    q = nz * r; e = __builtin_fmaf(-d, q, nz); q = __builtin_fmaf(e, r, q); e = __builtin_fmaf(-d, q, nz);
+    uz = __builtin_fmaf(e, r, q);
+}
+
 #endif
 
-// The two roots b -/+ q of one ray/sphere pair; FAST uses sqrt_rn_markstein on the device.
-// sqrt_rn_markstein differs from sqrtf() for exactly one input, +inf (NaN instead of +inf); an
+// The two roots b -/+ q of one ray/sphere pair; FAST uses sqrt_rn_rsq1 on the device.
+// sqrt_rn_rsq1 differs from sqrtf() for exactly one input, +inf (NaN instead of +inf); an
 // infinite discriminant makes t = +inf with sqrtf() and kMissT with the NaN, and neither can win
 // the strict '<' arg-min against tmin <= kMissT, so the selected sphere and tmin are unchanged.
 template <bool FAST>
@@ -151,7 +176,7 @@ APT_HD void intersect_roots(float cx, float cy, float cz, float r2, float ox, fl
     disc = disc - c;
     float q;
 #if defined(__HIP_DEVICE_COMPILE__)
-    if (FAST) q = sqrt_rn_markstein(disc, amin);
+    if (FAST) q = sqrt_rn_rsq1(disc, amin);
     else
 #endif
         q = sqrtf(disc);
@@ -252,7 +277,17 @@ APT_HD void shade_and_reflect(PathState &s, float tmin, float cx, float cy, floa
     else
 #endif
         L = sqrtf(L);                                           // :658
-    float ux = nx / L, uy = ny / L, uz = nz / L;                // :664-666 IEEE divide
+    float ux, uy, uz;                                           // :664-666 IEEE divide
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (FAST) {
+        bool ok = true;
+        div3_shared(nx, ny, nz, L, ux, uy, uz, ok);
+        if (!ok) *amin = 0.0f;                                  // forces the exact re-run of this bounce
+    } else
+#endif
+    {
+        ux = nx / L; uy = ny / L; uz = nz / L;
+    }
     float dot;
     if (MODE == kModeOracle) {                                  // np.dot, gen_data.py:349
         float p0 = s.dx * ux, p1 = s.dy * uy, p2 = s.dz * uz;

@@ -29,6 +29,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <string>
 #include <vector>
@@ -44,6 +45,8 @@ constexpr int kBlock = 256;      // 4 waves
 constexpr int kTile = 1024;      // spheres per LDS tile (16 KB)
 constexpr int kMaxLeaves = 64;   // pairwise-sum leaves -> samples <= 8192
 constexpr int kMaxStack = 8;
+constexpr int kStackSlots = kBlock / 8; // one pairwise-sum stack per sub-pixel group (its 8 lanes hold equal values)
+constexpr uint32_t kRefillLanes = 32; // default: lanes with an empty ray slot that trigger a wave-wide ray-generate
 
 struct Scene8 { // wave-uniform registers (SGPRs)
     float cx[8], cy[8], cz[8], r2[8];
@@ -54,11 +57,13 @@ struct TraceArgs {
     uint32_t depth;
     int32_t light;
     float eps, gain;
+    uint32_t refill_lanes;      // compaction: batch size that triggers ray-generate (tuning knob)
     unsigned long long *traced; // optional device counter of traced segments
 };
 
 struct LeafProg { // numpy pairwise_sum recursion flattened (see build_leaves)
     uint32_t nleaves;
+    uint32_t maxleaf;          // longest leaf (sizes the refill colour queue)
     uint32_t leaf[kMaxLeaves]; // len | ncomb << 16 (dwords: wave-uniform s_load from the kernarg segment)
     __host__ __device__ uint32_t len(uint32_t i) const { return leaf[i] & 0xffffu; }
     __host__ __device__ uint32_t ncomb(uint32_t i) const { return leaf[i] >> 16; }
@@ -234,9 +239,16 @@ __global__ __launch_bounds__(kBlock) void render_frame_kernel(const float *__res
                                                               TraceArgs ta, LeafProg lp) {
     __shared__ float4 tab[16];
     __shared__ float4 tile[NS8 ? 1 : kTile];
-    extern __shared__ float stack_lds[]; // [kMaxStack][3][kBlock] when lp.nleaves > 1
+    extern __shared__ float dyn_lds[];
+    float *stack_lds = dyn_lds;                                            // [kMaxStack][3][kStackSlots] when lp.nleaves > 1
+    float *queue_lds = dyn_lds + (lp.nleaves > 1 ? kMaxStack * 3 * kStackSlots : 0); // [waves][3][8*maxleaf] (refill)
+    // The camera frame (12 doubles) is only needed by ray-generate; parked in LDS it does not
+    // occupy 24 SGPRs across the bounce loop (they spilled to VGPR lanes otherwise).
+    __shared__ Camera cam;
+    if (threadIdx.x < 12) (&cam.pos[0])[threadIdx.x] = (&fa.cam.pos[0])[threadIdx.x];
     Scene8 sc;
     if (NS8) load_scene8(sph, sc, tab);
+    else __syncthreads();
 
     const uint32_t lane = threadIdx.x & 63;
     const uint64_t L = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -254,7 +266,7 @@ __global__ __launch_bounds__(kBlock) void render_frame_kernel(const float *__res
         double u1, u2;
         path_uniforms(fa.seed, pbase + k, u1, u2);
         float ray[6];
-        camera_ray(fa.cam, fa.width, fa.height, pi, pj, sy, sx, u1, u2, ray);
+        camera_ray(cam, fa.width, fa.height, pi, pj, sy, sx, u1, u2, ray);
         PathState s;
         path_init(s, ray[0], ray[1], ray[2], ray[3], ray[4], ray[5]);
         traced += NS8 ? trace_ns8<MODE, RETIRE>(sc, tab, s, valid, ta)
@@ -276,10 +288,111 @@ __global__ __launch_bounds__(kBlock) void render_frame_kernel(const float *__res
             }
         } else {          // 8 <= n <= 128: r[j] chains, tree, tail
             const uint32_t nfull = n & ~7u;
-            sample(start + j, acc);
-            for (uint32_t i8 = 8; i8 < nfull; i8 += 8) {
-                sample(start + i8 + j, c);
-                acc[0] = acc[0] + c[0]; acc[1] = acc[1] + c[1]; acc[2] = acc[2] + c[2];
+            if (RETIRE && NS8) {
+                // Active-ray compaction with a wave-level work queue.  The 8 sub-pixel groups of the
+                // wave have 8*nfull samples in this leaf; instead of binding sample k of group g to
+                // lane (g, k mod 8), any lane that runs out of work takes the next unissued sample:
+                // a ballot of the lanes with an empty one-ray slot, a prefix count (mbcnt) as the
+                // rank inside the batch, item = next + rank.  Finished colours are parked in a
+                // per-wave LDS array indexed by the sample, and lane (g, j) then adds its own chain
+                // j, 8+j, ... from there IN ORDER, so numpy's summation order is untouched and the
+                // frame stays bit-identical.  Ray-generate (float64, the expensive part) runs for
+                // the whole wave only when >= kRefillLanes lanes want a ray or nothing else is left.
+                float *colq = queue_lds + (size_t)(threadIdx.x >> 6) * 3u * 8u * lp.maxleaf; // [3][8*maxleaf]
+                const uint32_t total = 8u * nfull;        // items of this wave in this leaf (uniform)
+                const uint32_t qstride = 8u * lp.maxleaf;
+                uint32_t next = 0;                        // first unissued item (uniform)
+                uint32_t depth_left = 0, cur_item = 0, slot_item = 0;
+                uint32_t n_bounce_exec = 0, n_gen_exec = 0; // wave-level executions (statistics only)
+                float slot[6];
+                bool slot_full = false, slot_valid = false, cur_valid = false;
+                PathState s;
+                path_init(s, 0.f, 0.f, 0.f, 0.f, 0.f, 1.f);
+                for (;;) {
+                    const bool want = !slot_full;
+                    const unsigned long long wants = __ballot(want);
+                    const bool busy_any = __any(depth_left != 0 || slot_full);
+                    if (next < total && wants && ((uint32_t)__popcll(wants) >= ta.refill_lanes || !busy_any)) {
+                        ++n_gen_exec;
+                        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(wants >> 32),
+                                              __builtin_amdgcn_mbcnt_lo((uint32_t)wants, 0u));
+                        const uint32_t remaining = total - next;
+                        const bool take = want && rank < remaining;
+                        // group coordinates come from the first lane of the item's group; every lane
+                        // of the wave takes part in the shuffles (a masked-off source lane would
+                        // return garbage), lanes that do not take an item use item 0
+                        const uint32_t item = take ? next + rank : 0u;
+                        const uint32_t g = item / nfull, k = item - g * nfull;
+                        const int src = (int)(8u * g);
+                        const uint32_t gpi = __shfl(pi, src, 64), gpj = __shfl(pj, src, 64);
+                        const uint32_t gsub = __shfl(sub, src, 64);
+                        const uint32_t blo = __shfl((uint32_t)pbase, src, 64), bhi = __shfl((uint32_t)(pbase >> 32), src, 64);
+                        const bool gvalid = __shfl((int)valid, src, 64) != 0;
+                        if (take) {
+                            slot_valid = gvalid;
+                            double u1, u2;
+                            path_uniforms(fa.seed, (((uint64_t)bhi << 32) | blo) + start + k, u1, u2);
+                            camera_ray(cam, fa.width, fa.height, gpi, gpj, gsub >> 1, gsub & 1u, u1, u2, slot);
+                            slot_item = item;
+                            slot_full = true;
+                        }
+                        next += min((uint32_t)__popcll(wants), remaining);
+                    }
+                    if (depth_left == 0 && slot_full) { // start the waiting ray
+                        path_init(s, slot[0], slot[1], slot[2], slot[3], slot[4], slot[5]);
+                        cur_item = slot_item;
+                        cur_valid = slot_valid;
+                        depth_left = ta.depth;
+                        slot_full = false;
+                        if (ta.depth == 0 || !cur_valid) { // depth 0, or a group past the image: colour = gain
+                            depth_left = 0;
+                            colq[cur_item] = ta.gain; colq[qstride + cur_item] = ta.gain; colq[2 * qstride + cur_item] = ta.gain;
+                        }
+                    }
+                    const bool active = depth_left != 0;
+                    if (!__any(active)) {
+                        if (next >= total && !__any(slot_full)) break;
+                        continue;
+                    }
+                    ++n_bounce_exec;
+                    PathState nx;
+                    if (__builtin_expect(__any(bounce_ns8<MODE, true>(sc, tab, s, nx, ta)), 0)) {
+                        asm volatile("" ::: "memory");
+                        (void)bounce_ns8<MODE, false>(sc, tab, s, nx, ta);
+                    }
+                    if (active) {
+                        s = nx;
+                        ++traced;
+                        --depth_left;
+                        if (depth_left == 0 || path_finished(s)) {
+                            depth_left = 0;
+                            colq[cur_item] = s.rx * ta.gain;
+                            colq[qstride + cur_item] = s.ry * ta.gain;
+                            colq[2 * qstride + cur_item] = s.rz * ta.gain;
+                        }
+                    }
+                }
+                __syncthreads(); // colours of the whole leaf are in LDS (only wave-local data is read back)
+                {   // lane (g, j) adds samples j, 8+j, ... of its own group, in order: numpy's r[j] chain
+                    const uint32_t base = (lane >> 3) * nfull + j;
+#pragma unroll
+                    for (int ch = 0; ch < 3; ++ch) acc[ch] = colq[ch * qstride + base];
+                    for (uint32_t i8 = 8; i8 < nfull; i8 += 8) {
+#pragma unroll
+                        for (int ch = 0; ch < 3; ++ch) acc[ch] = acc[ch] + colq[ch * qstride + base + i8];
+                    }
+                }
+                __syncthreads(); // before the next leaf reuses the array
+                if (ta.traced && lane == 0) { // lane-slots spent: executions x 64
+                    atomicAdd(ta.traced + 1, 64ull * n_bounce_exec);
+                    atomicAdd(ta.traced + 2, 64ull * n_gen_exec);
+                }
+            } else {
+                sample(start + j, acc);
+                for (uint32_t i8 = 8; i8 < nfull; i8 += 8) {
+                    sample(start + i8 + j, c);
+                    acc[0] = acc[0] + c[0]; acc[1] = acc[1] + c[1]; acc[2] = acc[2] + c[2];
+                }
             }
 #pragma unroll
             for (int ch = 0; ch < 3; ++ch) { // ((r0+r1)+(r2+r3)) + ((r4+r5)+(r6+r7))
@@ -303,22 +416,22 @@ __global__ __launch_bounds__(kBlock) void render_frame_kernel(const float *__res
             res[0] = acc[0]; res[1] = acc[1]; res[2] = acc[2];
         } else { // pairwise(left) + pairwise(right), innermost first
 #pragma unroll
-            for (int ch = 0; ch < 3; ++ch) stack_lds[(sp * 3 + ch) * kBlock + threadIdx.x] = acc[ch];
+            for (int ch = 0; ch < 3; ++ch) stack_lds[(sp * 3 + ch) * kStackSlots + (threadIdx.x >> 3)] = acc[ch];
             ++sp;
             for (uint32_t m = 0; m < lp.ncomb(leaf); ++m) {
                 --sp;
 #pragma unroll
                 for (int ch = 0; ch < 3; ++ch) {
-                    const float a = stack_lds[((sp - 1) * 3 + ch) * kBlock + threadIdx.x];
-                    const float b = stack_lds[(sp * 3 + ch) * kBlock + threadIdx.x];
-                    stack_lds[((sp - 1) * 3 + ch) * kBlock + threadIdx.x] = a + b;
+                    const float a = stack_lds[((sp - 1) * 3 + ch) * kStackSlots + (threadIdx.x >> 3)];
+                    const float b = stack_lds[(sp * 3 + ch) * kStackSlots + (threadIdx.x >> 3)];
+                    stack_lds[((sp - 1) * 3 + ch) * kStackSlots + (threadIdx.x >> 3)] = a + b;
                 }
             }
         }
     }
     if (lp.nleaves > 1) {
 #pragma unroll
-        for (int ch = 0; ch < 3; ++ch) res[ch] = stack_lds[ch * kBlock + threadIdx.x];
+        for (int ch = 0; ch < 3; ++ch) res[ch] = stack_lds[ch * kStackSlots + (threadIdx.x >> 3)];
     }
 
     // decode_color: data_visualization.py:36-57
@@ -436,11 +549,51 @@ __global__ __launch_bounds__(kBlock) void selftest_sqrt_kernel(int variant, uint
 #endif
 }
 
+// ---- kernel: self-test of the shared-reciprocal divide --------------------------------------
+// Operand set i of [begin, begin+count): three numerators and one divisor built from a counter
+// hash; a quarter of the sets use special mantissas (all ones, 1.0, powers of two, one-bit
+// neighbours) and exponents at the edges of the accepted range.  Every accepted set must give
+// the three quotients of the plain `/` bit for bit.
+__global__ __launch_bounds__(kBlock) void selftest_div3_kernel(uint64_t begin, uint64_t count,
+                                                               unsigned long long *result) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    unsigned long long bad = 0, first = ~0ull, accepted = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < count; i += stride) {
+        uint64_t h = splitmix64(begin + i);
+        float v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            h = splitmix64(h);
+            uint32_t man = (uint32_t)h & 0x7fffffu, ex = 127u - 44u + (uint32_t)((h >> 23) % 89u), sg = (uint32_t)(h >> 63);
+            if (((begin + i) & 3u) == 0u) {
+                const uint32_t pick = (uint32_t)(h >> 40) & 7u;
+                man = pick == 0 ? 0x7fffffu : pick == 1 ? 0u : pick == 2 ? 1u : pick == 3 ? 0x7ffffeu
+                    : pick == 4 ? 0x400000u : pick == 5 ? 0x3fffffu : pick == 6 ? 0x400001u : man;
+                if (((h >> 44) & 3u) == 0u) ex = ((h >> 46) & 1u) ? 127u - 40u : 127u + 39u;
+            }
+            v[k] = __uint_as_float((sg << 31) | (ex << 23) | man);
+        }
+        float ux, uy, uz;
+        bool ok = true;
+        div3_shared(v[0], v[1], v[2], v[3], ux, uy, uz, ok);
+        if (!ok) continue;
+        ++accepted;
+        const float wx = v[0] / v[3], wy = v[1] / v[3], wz = v[2] / v[3];
+        if (__float_as_uint(ux) != __float_as_uint(wx) || __float_as_uint(uy) != __float_as_uint(wy) ||
+            __float_as_uint(uz) != __float_as_uint(wz)) { ++bad; if (first == ~0ull) first = begin + i; }
+    }
+    if (bad) { atomicAdd(&result[0], bad); atomicMin(&result[1], first); }
+    atomicAdd(&result[2], accepted);
+#endif
+}
+
 // ---- host side ----------------------------------------------------------------------------
 thread_local std::string g_err;
 apt_render_params g_default;
 bool g_default_init = false;
 unsigned long long *g_trace_counter = nullptr;
+uint32_t g_refill_lanes = kRefillLanes;
 
 int fail(int code, const char *fmt, const char *detail = "") {
     char buf[256];
@@ -464,7 +617,10 @@ int make_leaf_prog(uint32_t samples, LeafProg &lp) {
     if (v.size() > (size_t)kMaxLeaves) return fail(APT_ERR_ARG, "samples too large for the pairwise plan (max 8192)%s");
     memset(&lp, 0, sizeof lp);
     lp.nleaves = (uint32_t)v.size();
-    for (size_t i = 0; i < v.size(); ++i) lp.leaf[i] = v[i].first | (v[i].second << 16);
+    for (size_t i = 0; i < v.size(); ++i) {
+        lp.leaf[i] = v[i].first | (v[i].second << 16);
+        lp.maxleaf = v[i].first > lp.maxleaf ? v[i].first : lp.maxleaf;
+    }
     return APT_OK;
 }
 
@@ -484,6 +640,7 @@ TraceArgs make_trace_args(const apt_render_params *p) {
     TraceArgs ta;
     ta.ns = p->num_spheres; ta.depth = p->depth; ta.light = p->light_index;
     ta.eps = p->eps; ta.gain = p->gain; ta.traced = g_trace_counter;
+    ta.refill_lanes = g_refill_lanes;
     return ta;
 }
 
@@ -551,6 +708,21 @@ int apt_selftest_sqrt(int variant, void *stream, uint64_t first_bits, uint64_t c
     return e == hipSuccess ? APT_OK : hip_fail(e);
 }
 
+int apt_selftest_div3(void *stream, uint64_t first, uint64_t count, uint64_t *device_result3) {
+    if (!device_result3) return fail(APT_ERR_ARG, "apt_selftest_div3: bad arguments%s");
+    if (count == 0) return APT_OK;
+    hipLaunchKernelGGL(selftest_div3_kernel, dim3(256 * 16), dim3(kBlock), 0, (hipStream_t)stream, first, count,
+                       (unsigned long long *)device_result3);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? APT_OK : hip_fail(e);
+}
+
+int apt_set_refill_lanes(uint32_t lanes) {
+    if (lanes < 1 || lanes > 64) return fail(APT_ERR_ARG, "apt_set_refill_lanes: 1..64%s");
+    g_refill_lanes = lanes;
+    return APT_OK;
+}
+
 int apt_set_trace_counter(uint64_t *device_counter) {
     g_trace_counter = (unsigned long long *)device_counter;
     return APT_OK;
@@ -613,7 +785,8 @@ int render_frame(const apt_render_params *p, void *stream, const float *spheres,
     fa.width = p->width; fa.height = p->height; fa.samples = p->samples; fa.seed = p->seed;
     fa.pixel_begin = pixel_begin; fa.pixel_count = pixel_count; fa.fb = fb; fa.fb_u8 = fb_u8;
     const bool retire = p->flags & APT_FLAG_RETIRE;
-    const size_t lds = lp.nleaves > 1 ? (size_t)kMaxStack * 3 * kBlock * sizeof(float) : 0;
+    size_t lds = lp.nleaves > 1 ? (size_t)kMaxStack * 3 * kStackSlots * sizeof(float) : 0;
+    if (retire && ns8 && group == 8) lds += (size_t)(kBlock / 64) * 3 * 8 * lp.maxleaf * sizeof(float); // colour queue
     const dim3 grid((unsigned)blocks);
     if (p->mode == APT_MODE_ORACLE) {
         if (ns8) launch_frame_g<kModeOracle, true>(group, retire, grid, lds, st, spheres, fa, ta, lp);

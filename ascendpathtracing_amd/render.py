@@ -105,7 +105,7 @@ class TraceCounter:
     """Optional device counter of traced ray segments (for reporting under APT_FLAG_RETIRE)."""
 
     def __init__(self, device="cuda"):
-        self.buf = torch.zeros(1, dtype=torch.int64, device=device)
+        self.buf = torch.zeros(4, dtype=torch.int64, device=device)  # [0] segments, [1..2] refill statistics
 
     def __enter__(self):
         self.buf.zero_()
@@ -118,7 +118,13 @@ class TraceCounter:
 
     @property
     def value(self):
-        return int(self.buf.item())
+        return int(self.buf[0].item())
+
+    @property
+    def stats(self):
+        """(traced segments, lane-slots spent in bounce executions, lane-slots spent in ray-generate) --
+        the last two only from the refill loop of render_frame with APT_FLAG_RETIRE."""
+        return tuple(int(x) for x in self.buf[:3].tolist())
 
 
 def selftest_sqrt(variant=0, first_bits=0, count=1 << 32, stream=None):
@@ -130,3 +136,18 @@ def selftest_sqrt(variant=0, first_bits=0, count=1 << 32, stream=None):
     torch.cuda.synchronize()
     bad, first = res.tolist()
     return bad, first & 0xFFFFFFFF
+
+
+def selftest_div3(first=0, count=1 << 32, stream=None):
+    """Shared-reciprocal divide vs `/` on hashed operand sets: -> (mismatches, first bad, accepted)."""
+    require_gpu()
+    res = torch.tensor([0, -1, 0], dtype=torch.int64, device="cuda")
+    check(lib().apt_selftest_div3(_stream_handle(stream), ctypes.c_uint64(first), ctypes.c_uint64(count),
+                                  ctypes.c_void_p(res.data_ptr())), "apt_selftest_div3")
+    torch.cuda.synchronize()
+    return tuple(res.tolist())
+
+
+def set_refill_lanes(lanes):
+    """Compaction batch threshold (1..64, default 32); speed only, results do not depend on it."""
+    check(lib().apt_set_refill_lanes(ctypes.c_uint32(lanes)), "apt_set_refill_lanes")

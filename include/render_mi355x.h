@@ -150,18 +150,30 @@ int apt_gen_scene_host(uint32_t num_spheres, uint64_t seed, float *spheres,
 int apt_write_ppm(const char *path, uint32_t width, uint32_t height, const uint8_t *fb_u8);
 
 /* ---- diagnostics ------------------------------------------------------------------- */
-/* Optional DEVICE uint64 counter to which every render launch adds the number of ray
- * segments it actually traced (== paths*depth unless APT_FLAG_RETIRE).  NULL disables it.
+/* Optional DEVICE uint64[4] statistics block.  [0] += ray segments actually traced by every
+ * render launch (== paths*depth unless APT_FLAG_RETIRE); [1], [2] += lane-slots (64 per wave-level
+ * execution) spent in bounce / ray-generate by the refill loop of render_frame.  NULL disables it.
  * The caller zeroes it; process-wide. */
 int apt_set_trace_counter(uint64_t *device_counter);
 
 /* Self-test of the hot loop's fast correctly-rounded sqrt: compares it with sqrtf() for every
  * float whose bit pattern lies in [first_bits, first_bits+count) (count = 2^32 covers all).
- * variant 0 = the sequence the kernels use, 1 = the Markstein candidate.
+ * variant 0 = neighbour check (shade), 1..3 = FMA-correction candidates; the intersect loop uses 2.
  * device_result2[0] += number of mismatches, device_result2[1] = min(first mismatching bits);
  * the caller initialises them to 0 and ~0. */
 int apt_selftest_sqrt(int variant, void *stream, uint64_t first_bits, uint64_t count,
                       uint64_t *device_result2);
+
+/* Self-test of the shared-reciprocal divide of the shading step against the plain `/` on
+ * `count` hashed operand sets starting at counter `first`.  device_result3[0] += mismatches,
+ * [1] = min(first mismatching counter), [2] += sets inside the accepted operand range.
+ * Initialise to 0, ~0, 0. */
+int apt_selftest_div3(void *stream, uint64_t first, uint64_t count, uint64_t *device_result3);
+
+/* Tuning knob of the APT_FLAG_RETIRE compaction in render_frame: a wave runs its (expensive,
+ * float64) ray-generate when at least `lanes` of its 64 lanes have an empty ray slot (default
+ * 32).  Speed only: results are bit-identical for every value.  Process-wide. */
+int apt_set_refill_lanes(uint32_t lanes);
 
 int         apt_abi_version(void);
 const char *apt_last_error(void);       /* thread-local, "" when none */

@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""Times the other BASELINE.json configurations on one MI355X (bench.py covers configs[1] = C2):
+C1 (256x256, 4 spp, D4, buffer mode incl. the exact reference boundary), C4 (10k-sphere scene,
+LDS-staged traversal), C5 (32 bounces, with and without result-preserving retirement).  One
+JSON line per case.   python profiles/configs_bench.py [--spp-c4 S]"""
+import argparse, json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import ascendpathtracing_amd as apt
+from ascendpathtracing_amd import gen_data, render
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--spp-c4", type=int, default=8, help="S for the 10k-sphere case (64 = full 256 spp, ~8x longer)")
+ap.add_argument("--reps", type=int, default=3)
+args = ap.parse_args()
+
+
+def timeit(fn, reps):
+    fn(); torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    for a, b in ev:
+        a.record(); fn(); b.record()
+    torch.cuda.synchronize()
+    return min(a.elapsed_time(b) for a, b in ev)
+
+
+def report(name, ms, segments, ns, extra=None):
+    flops = segments * (20 * ns + 33)
+    out = {"case": name, "kernel_ms": round(ms, 3), "segments_nominal": segments, "Mray_per_s": round(segments / ms / 1e3, 1),
+           "pair_tests_per_s": round(segments * ns / ms * 1e3, 0), "achieved_TFLOPs": round(flops / ms / 1e9, 3),
+           "frac_of_157.3": round(flops / ms / 1e9 / 157.3, 4)}
+    out.update(extra or {})
+    print(json.dumps(out), flush=True)
+
+
+sph8 = torch.from_numpy(gen_data.gen_spheres()).cuda()
+# C1: buffer mode, the exact render_do boundary (rays from gen_rays, MT19937)
+rays = torch.from_numpy(gen_data.gen_rays(256, 256, 1, seed=0).ravel()).cuda()
+for mode, name in ((apt.APT_MODE_KERNEL, "K"), (apt.APT_MODE_ORACLE, "O")):
+    p = apt.make_params(256, 256, 1, depth=4, mode=mode)
+    colors = torch.empty(3 * p.num_paths, device="cuda")
+    ms = timeit(lambda: render.render_do_ex(p, None, rays, sph8, colors), args.reps)
+    report(f"C1 256x256 4spp D4 buffer mode {name}-mode", ms, p.num_paths * 4, 8)
+# C2 / C5: frame mode
+for d, flags, name in ((8, 0, "C2 D8"), (8, apt.APT_FLAG_RETIRE, "C2 D8 retire"), (32, 0, "C5 D32"),
+                       (32, apt.APT_FLAG_RETIRE, "C5 D32 retire")):
+    p = apt.make_params(1920, 1080, 64, depth=d, flags=flags)
+    with render.TraceCounter() as tc:
+        ms = timeit(lambda: render.render_frame(p, sph8), 1)
+    traced = tc.value // 2
+    ms = timeit(lambda: render.render_frame(p, sph8), args.reps)
+    report(f"{name} 1080p 256spp", ms, p.num_paths * d, 8, {"segments_traced": traced})
+# C4: 10k spheres
+scene = torch.from_numpy(gen_data.gen_scene(10000, seed=1)).cuda()
+for flags, name in ((0, ""), (apt.APT_FLAG_RETIRE, " retire")):
+    p = apt.make_params(1920, 1080, args.spp_c4, depth=8, num_spheres=10000, flags=flags)
+    ms = timeit(lambda: render.render_frame(p, scene), 1)
+    report(f"C4 10k spheres 1080p {4 * args.spp_c4}spp D8{name}", ms, p.num_paths * 8, 10000)
