@@ -136,6 +136,28 @@ __device__ __forceinline__ uint32_t trace_ns8(const Scene8 &sc, const float4 *ta
 }
 
 // ---- trace: any scene, LDS-staged tiles -------------------------------------------------
+// Discriminants of TWO spheres per instruction: the tile is stored as sphere pairs,
+//   tile[2p]   = (cx[2p], cx[2p+1], cy[2p], cy[2p+1])      tile[2p+1] = (cz[2p], cz[2p+1], r2[2p], r2[2p+1])
+// so every operation of intersect_pre becomes one v_pk_{add,mul}_f32 over a register pair, the
+// ray component being broadcast to both halves by op_sel (no register shuffles).  Packed fp32
+// ops round exactly like the scalar ones, element by element; contraction is off.
+typedef float f2 __attribute__((ext_vector_type(2)));
+struct HitPre2 { f2 b, disc; };
+__device__ __forceinline__ HitPre2 intersect_pre2(const float4 a, const float4 c4, const PathState &s) {
+    const f2 cx = {a.x, a.y}, cy = {a.z, a.w}, cz = {c4.x, c4.y}, r2 = {c4.z, c4.w};
+    const f2 ocx = cx - s.ox, ocy = cy - s.oy, ocz = cz - s.oz;
+    f2 b = ocx * s.dx;
+    b = b + ocy * s.dy;
+    b = b + ocz * s.dz;
+    f2 c = ocx * ocx;
+    c = c + ocy * ocy;
+    c = c + ocz * ocz;
+    c = c - r2;
+    f2 disc = b * b;
+    disc = disc - c;
+    return {b, disc};
+}
+
 // Every thread of the workgroup must call this together (it contains barriers).
 template <int MODE, bool RETIRE>
 __device__ __forceinline__ uint32_t trace_dyn(const float *__restrict__ sph, float4 *tile, PathState &s, bool valid,
@@ -152,15 +174,41 @@ __device__ __forceinline__ uint32_t trace_dyn(const float *__restrict__ sph, flo
         for (uint32_t base = 0; base < ns; base += kTile) {
             const uint32_t n = min((uint32_t)kTile, ns - base);
             __syncthreads(); // previous tile fully consumed
-            for (uint32_t k = threadIdx.x; k < n; k += kBlock)
-                tile[k] = make_float4(cx[base + k], cy[base + k], cz[base + k], r2[base + k]);
+            {   // stage: coalesced plane loads, pair-interleaved LDS layout, NaN spheres pad the tail to a
+                // multiple of 4 (a NaN discriminant is never >= 0, so a pad can never hit)
+                float *tf = reinterpret_cast<float *>(tile);
+                const uint32_t n4 = (n + 3u) & ~3u;
+                for (uint32_t k = threadIdx.x; k < n4; k += kBlock) {
+                    const bool real = k < n;
+                    const float qn = __uint_as_float(0x7fc00000u);
+                    const uint32_t o = (k >> 1) * 8u + (k & 1u);
+                    tf[o] = real ? cx[base + k] : qn;
+                    tf[o + 2] = real ? cy[base + k] : qn;
+                    tf[o + 4] = real ? cz[base + k] : qn;
+                    tf[o + 6] = real ? r2[base + k] : qn;
+                }
+            }
             __syncthreads();
-            for (uint32_t k = 0; k < n; ++k) {
-                const float4 sp = tile[k]; // wave-uniform address: LDS broadcast
-                const HitPre h = intersect_pre(sp.x, sp.y, sp.z, sp.w, s.ox, s.oy, s.oz, s.dx, s.dy, s.dz);
-                if (__any(h.disc >= 0.0f)) { // a negative discriminant yields kMissT, which never wins
-                    const float t = intersect_post(h, ta.eps);
-                    if (t < tmin) { tmin = t; idx = (int)(base + k); }
+            // Four spheres per step: four wave-uniform ds_read_b128 broadcasts in flight together, two
+            // packed discriminant evaluations, ONE test "can any lane hit any of the four?".  A
+            // negative discriminant yields kMissT, which never wins the strict '<', so skipping the
+            // sqrt/root half for misses is result preserving; hits are then taken in ascending
+            // sphere order, which keeps the lowest-index-on-ties rule.
+            auto hit = [&](float b, float disc, uint32_t sphere) {
+                if (__any(disc >= 0.0f)) {
+                    const float t = intersect_post(HitPre{b, disc}, ta.eps);
+                    if (t < tmin) { tmin = t; idx = (int)sphere; }
+                }
+            };
+            for (uint32_t k = 0; k < n; k += 4) {
+                const float4 a0 = tile[k], c0 = tile[k + 1], a1 = tile[k + 2], c1 = tile[k + 3];
+                const HitPre2 h01 = intersect_pre2(a0, c0, s), h23 = intersect_pre2(a1, c1, s);
+                const float m = fmaxf(fmaxf(h01.disc.x, h01.disc.y), fmaxf(h23.disc.x, h23.disc.y)); // NaNs drop out
+                if (__any(m >= 0.0f)) {
+                    hit(h01.b.x, h01.disc.x, base + k);
+                    hit(h01.b.y, h01.disc.y, base + k + 1);
+                    hit(h23.b.x, h23.disc.x, base + k + 2);
+                    hit(h23.b.y, h23.disc.y, base + k + 3);
                 }
             }
         }
