@@ -69,6 +69,31 @@ struct LeafProg { // numpy pairwise_sum recursion flattened (see build_leaves)
     __host__ __device__ uint32_t ncomb(uint32_t i) const { return leaf[i] >> 16; }
 };
 
+// Discriminants of TWO spheres per instruction: the tile is stored as sphere pairs,
+//   tile[2p]   = (cx[2p], cx[2p+1], cy[2p], cy[2p+1])      tile[2p+1] = (cz[2p], cz[2p+1], r2[2p], r2[2p+1])
+// so every operation of intersect_pre becomes one v_pk_{add,mul}_f32 over a register pair, the
+// ray component being broadcast to both halves by op_sel (no register shuffles).  Packed fp32
+// ops round exactly like the scalar ones, element by element; contraction is off.
+typedef float f2 __attribute__((ext_vector_type(2)));
+struct HitPre2 { f2 b, disc; };
+__device__ __forceinline__ HitPre2 intersect_pre2(const f2 cx, const f2 cy, const f2 cz, const f2 r2, const PathState &s) {
+    const f2 ocx = cx - s.ox, ocy = cy - s.oy, ocz = cz - s.oz;
+    f2 b = ocx * s.dx;
+    b = b + ocy * s.dy;
+    b = b + ocz * s.dz;
+    f2 c = ocx * ocx;
+    c = c + ocy * ocy;
+    c = c + ocz * ocz;
+    c = c - r2;
+    f2 disc = b * b;
+    disc = disc - c;
+    return {b, disc};
+}
+__device__ __forceinline__ HitPre2 intersect_pre2(const float4 a, const float4 c4, const PathState &s) {
+    return intersect_pre2(f2{a.x, a.y}, f2{a.z, a.w}, f2{c4.x, c4.y}, f2{c4.z, c4.w}, s);
+}
+
+
 // ---- trace: reference scene (Ns == 8) ----------------------------------------------------
 // One bounce: 8 intersections (sphere operands in SGPRs), arg-min, gather, shade.
 // FAST: exact fast sqrt sequences (pt_core.h) and, when eps permits, the integer-key arg-min.
@@ -83,11 +108,18 @@ __device__ __forceinline__ bool bounce_ns8(const Scene8 &sc, const float4 *tab, 
         RootKey key;
         rootkey_init(key, ta.eps, miss);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) { // rt_helper.h:457-467
-            float t0, t1;
-            intersect_roots<true>(sc.cx[k], sc.cy[k], sc.cz[k], sc.r2[k], s.ox, s.oy, s.oz, s.dx, s.dy, s.dz, t0, t1,
-                                  amin);
-            rootkey_update(key, t0, t1, k);
+        for (int k = 0; k < 8; k += 2) { // rt_helper.h:457-467, two spheres per packed instruction
+            const HitPre2 h = intersect_pre2(f2{sc.cx[k], sc.cx[k + 1]}, f2{sc.cy[k], sc.cy[k + 1]},
+                                             f2{sc.cz[k], sc.cz[k + 1]}, f2{sc.r2[k], sc.r2[k + 1]}, s);
+            // sqrt_rn_rsq1 on both lanes of the pair (pt_core.h): y = x*r, hh = r/2, q = fma(fma(-y,y,x), hh, y)
+            amin = fminf(amin, fminf(fabsf(h.disc.x), fabsf(h.disc.y)));
+            const f2 r0 = {__builtin_amdgcn_rsqf(h.disc.x), __builtin_amdgcn_rsqf(h.disc.y)};
+            const f2 y = h.disc * r0, hh = r0 * 0.5f;
+            const f2 res = __builtin_elementwise_fma(-y, y, h.disc);
+            const f2 q = __builtin_elementwise_fma(res, hh, y);
+            const f2 t0 = h.b - q, t1 = h.b + q;
+            rootkey_update(key, t0.x, t1.x, k);
+            rootkey_update(key, t0.y, t1.y, k + 1);
         }
         tmin = rootkey_tmin(key);
         idx = key.idx;
@@ -119,11 +151,18 @@ __device__ __forceinline__ uint32_t trace_ns8(const Scene8 &sc, const float4 *ta
         const bool fin = RETIRE && (!valid || path_finished(s));
         if (RETIRE && __all(fin)) break;
         PathState n;
-        if (__builtin_expect(__any(bounce_ns8<MODE, true>(sc, tab, s, n, ta)), 0)) {
-            // some |sqrt argument| < 2^-96 in this wave: redo the bounce with sqrtf().  The empty
-            // volatile asm keeps the compiler from speculating this cold path into the hot block.
-            asm volatile("" ::: "memory");
-            (void)bounce_ns8<MODE, false>(sc, tab, s, n, ta);
+        bool redo = bounce_ns8<MODE, true>(sc, tab, s, n, ta);
+        if (__builtin_expect(__any(redo), 0)) {
+            // A lane left the validity range of the fast sequences (|sqrt argument| < 2^-96, divide
+            // operands outside [2^-40, 2^40]).  A lane whose path is already finished (alive bit
+            // cleared or throughput zero) cannot influence any output any more, so its request is
+            // ignored: deep all-miss paths (|n| ~ 1e20) are of that kind.  Otherwise redo the bounce
+            // with sqrtf() and '/'.  The empty volatile asm keeps this cold path out of the hot block.
+            redo = redo && !path_finished(s);
+            if (__any(redo)) {
+                asm volatile("" ::: "memory");
+                (void)bounce_ns8<MODE, false>(sc, tab, s, n, ta);
+            }
         }
         if (RETIRE) {
             if (!fin) { s = n; ++traced; }
@@ -136,28 +175,6 @@ __device__ __forceinline__ uint32_t trace_ns8(const Scene8 &sc, const float4 *ta
 }
 
 // ---- trace: any scene, LDS-staged tiles -------------------------------------------------
-// Discriminants of TWO spheres per instruction: the tile is stored as sphere pairs,
-//   tile[2p]   = (cx[2p], cx[2p+1], cy[2p], cy[2p+1])      tile[2p+1] = (cz[2p], cz[2p+1], r2[2p], r2[2p+1])
-// so every operation of intersect_pre becomes one v_pk_{add,mul}_f32 over a register pair, the
-// ray component being broadcast to both halves by op_sel (no register shuffles).  Packed fp32
-// ops round exactly like the scalar ones, element by element; contraction is off.
-typedef float f2 __attribute__((ext_vector_type(2)));
-struct HitPre2 { f2 b, disc; };
-__device__ __forceinline__ HitPre2 intersect_pre2(const float4 a, const float4 c4, const PathState &s) {
-    const f2 cx = {a.x, a.y}, cy = {a.z, a.w}, cz = {c4.x, c4.y}, r2 = {c4.z, c4.w};
-    const f2 ocx = cx - s.ox, ocy = cy - s.oy, ocz = cz - s.oz;
-    f2 b = ocx * s.dx;
-    b = b + ocy * s.dy;
-    b = b + ocz * s.dz;
-    f2 c = ocx * ocx;
-    c = c + ocy * ocy;
-    c = c + ocz * ocz;
-    c = c - r2;
-    f2 disc = b * b;
-    disc = disc - c;
-    return {b, disc};
-}
-
 // Every thread of the workgroup must call this together (it contains barriers).
 template <int MODE, bool RETIRE>
 __device__ __forceinline__ uint32_t trace_dyn(const float *__restrict__ sph, float4 *tile, PathState &s, bool valid,
@@ -404,7 +421,9 @@ __global__ __launch_bounds__(kBlock) void render_frame_kernel(const float *__res
                     }
                     ++n_bounce_exec;
                     PathState nx;
-                    if (__builtin_expect(__any(bounce_ns8<MODE, true>(sc, tab, s, nx, ta)), 0)) {
+                    bool redo = bounce_ns8<MODE, true>(sc, tab, s, nx, ta);
+                    redo = redo && active;
+                    if (__builtin_expect(__any(redo), 0)) { // exact re-run, see trace_ns8
                         asm volatile("" ::: "memory");
                         (void)bounce_ns8<MODE, false>(sc, tab, s, nx, ta);
                     }
