@@ -310,6 +310,27 @@ APT_HD void shade_and_reflect(PathState &s, float tmin, float cx, float cy, floa
     }
 }
 
+// ---- first-hit debug mode: scripts/gen_data.py:134-188 test_scene --------------------------
+// One ray against sphere k with test_scene's arithmetic: np.dot on float32 3-vectors (float64
+// accumulation of float32 products, rounded once), det = (b*b - dot(op,op)) + r2, miss when
+// det < 0.  Updates (mind, id) with the reference's t0-then-t1 rule (:163-168).
+APT_HD void test_scene_sphere(float cx, float cy, float cz, float r2, float ox, float oy, float oz, float dx, float dy,
+                              float dz, float eps, int k, float &mind, int &id) {
+    const float opx = cx - ox, opy = cy - oy, opz = cz - oz;              // :151
+    const float p0 = opx * dx, p1 = opy * dy, p2 = opz * dz;
+    double acc = 0.0 + (double)p0; acc = acc + (double)p1; acc = acc + (double)p2;
+    const float b = (float)acc;                                           // :153
+    const float q0 = opx * opx, q1 = opy * opy, q2 = opz * opz;
+    acc = 0.0 + (double)q0; acc = acc + (double)q1; acc = acc + (double)q2;
+    float det = b * b - (float)acc;                                       // :154
+    det = det + r2;
+    if (det < 0.0f) return;                                               // :155 (NaN falls through like NumPy)
+    det = sqrtf(det);
+    const float t0 = b - det, t1 = b + det;
+    if (t0 > eps && t0 < mind) { mind = t0; id = k; }                     // :163-165
+    else if (t1 > eps && t1 < mind) { mind = t1; id = k; }                // :166-168
+}
+
 // ---- ray generation (all float64, cast to float32 at the end: gen_data.py:71) ---------
 struct Camera { double pos[3], g[3], cx[3], cy[3]; };
 

@@ -520,6 +520,29 @@ __global__ __launch_bounds__(kBlock) void render_frame_kernel(const float *__res
     count_traced(ta, valid ? traced : 0);
 }
 
+// ---- kernel: first-hit debug oracle (gen_data.py:134-188 test_scene) ---------------------------
+// out[3][N]: emission of the light when it is the first hit, the sphere's colour otherwise, 0 when
+// nothing is hit.  One lane per ray, spheres read straight from the [10][Ns] planes (L2-resident).
+__global__ __launch_bounds__(kBlock) void test_scene_kernel(const float *__restrict__ rays,
+                                                            const float *__restrict__ sph, float *__restrict__ out,
+                                                            uint64_t n_total, uint32_t ns, int32_t light, float eps) {
+    const uint64_t p = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (p >= n_total) return;
+    const float ox = rays[p], oy = rays[n_total + p], oz = rays[2 * n_total + p];
+    const float dx = rays[3 * n_total + p], dy = rays[4 * n_total + p], dz = rays[5 * n_total + p];
+    float mind = kMissT;
+    int id = -1;
+    for (uint32_t k = 0; k < ns; ++k)
+        test_scene_sphere(sph[ns + k], sph[2 * (size_t)ns + k], sph[3 * (size_t)ns + k], sph[k], ox, oy, oz, dx, dy, dz,
+                          eps, (int)k, mind, id);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float v = 0.0f;
+        if (id >= 0) v = (id == light) ? sph[(size_t)(4 + c) * ns + id] : sph[(size_t)(7 + c) * ns + id]; // :175-180
+        out[(uint64_t)c * n_total + p] = v;
+    }
+}
+
 // ---- kernel: device gen_rays (counter RNG) -----------------------------------------------
 __global__ __launch_bounds__(kBlock) void gen_rays_kernel(Camera cam, uint32_t width, uint32_t height,
                                                           uint32_t samples, uint64_t seed, uint64_t n_total,
@@ -862,6 +885,19 @@ int render_frame(const apt_render_params *p, void *stream, const float *spheres,
         if (ns8) launch_frame_g<kModeKernel, true>(group, retire, grid, lds, st, spheres, fa, ta, lp);
         else launch_frame_g<kModeKernel, false>(group, retire, grid, lds, st, spheres, fa, ta, lp);
     }
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? APT_OK : hip_fail(e);
+}
+
+int apt_test_scene(const apt_render_params *p, void *stream, const float *rays, const float *spheres, float *out) {
+    int rc = check_params(p);
+    if (rc) return rc;
+    if (!rays || !spheres || !out) return fail(APT_ERR_ARG, "rays/spheres/out must be non-null%s");
+    const uint64_t n = (uint64_t)p->width * p->height * 4u * p->samples;
+    const uint64_t blocks = (n + kBlock - 1) / kBlock;
+    if (blocks > 0x7fffffffull) return fail(APT_ERR_ARG, "image too large for one launch%s");
+    hipLaunchKernelGGL(test_scene_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, rays, spheres,
+                       out, n, p->num_spheres, p->light_index, p->eps);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? APT_OK : hip_fail(e);
 }

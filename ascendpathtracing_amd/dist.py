@@ -75,8 +75,9 @@ class FrameShard:
 
     def gather(self, fb, u8, full_fb=None, full_u8=None, dst=0):
         """ONE collective: every rank's packed slice to `dst`, which scatters the slices into
-        the full framebuffer.  With world == 1 it is a local copy."""
-        if self.world == 1:
+        the full framebuffer.  Without a process group (single process) it is a local copy; with
+        one -- even of a single rank -- it goes through torch.distributed (RCCL on GPUs)."""
+        if self.world == 1 and not dist.is_initialized():
             if full_fb is not None:
                 full_fb.copy_(fb)
                 full_u8.copy_(u8)

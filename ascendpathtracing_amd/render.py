@@ -151,3 +151,14 @@ def selftest_div3(first=0, count=1 << 32, stream=None):
 def set_refill_lanes(lanes):
     """Compaction batch threshold (1..64, default 32); speed only, results do not depend on it."""
     check(lib().apt_set_refill_lanes(ctypes.c_uint32(lanes)), "apt_set_refill_lanes")
+
+
+def test_scene(params: RenderParams, rays, spheres, stream=None):
+    """First-hit debug mode (scripts/gen_data.py:134-188 test_scene) -> [3][N] tensor."""
+    require_gpu()
+    n = params.num_paths
+    out = torch.empty(3 * n, dtype=torch.float32, device=rays.device)
+    check(lib().apt_test_scene(ctypes.byref(params), _stream_handle(stream), _dev_f32(rays, "rays", 6 * n),
+                               _dev_f32(spheres, "spheres", sphere_floats(params.num_spheres)),
+                               _dev_f32(out, "out")), "apt_test_scene")
+    return out.view(3, -1)

@@ -120,6 +120,12 @@ int render_do_ex(const apt_render_params *p, void *stream,
 int render_frame(const apt_render_params *p, void *stream, const float *spheres,
                  uint64_t pixel_begin, uint64_t pixel_count, float *fb, uint8_t *fb_u8);
 
+/* First-hit debug mode, scripts/gen_data.py:134-188 test_scene: out [3][N] = emission of the
+ * light sphere when it is the nearest hit, the hit sphere's colour otherwise, 0 on a miss
+ * (test_scene's own arithmetic: float64-accumulated dot products). */
+int apt_test_scene(const apt_render_params *p, void *stream, const float *rays,
+                   const float *spheres, float *out);
+
 /* Device gen_rays with the counter-based generator: writes rays [6][N] planes for paths
  * [path_begin, path_begin+path_count) of the full buffer (same rays render_frame traces). */
 int apt_gen_rays_device(const apt_render_params *p, void *stream, float *rays);
