@@ -88,9 +88,9 @@ int apt_gen_rays_host(uint32_t width, uint32_t height, uint32_t samples, uint32_
                     for (uint32_t k = 0; k < samples; ++k, ++p) {
                         const double u1 = rng.next_double(); // r1 before r2: :37,:39
                         const double u2 = rng.next_double();
-                        float ray[6];
-                        apt::camera_ray(cam, width, height, i, j, sy, sx, u1, u2, ray);
-                        for (int m = 0; m < 6; ++m) rays[(uint64_t)m * n + p] = ray[m]; // SoA: :65-71
+                        const apt::Ray ray = apt::camera_ray(cam, width, height, i, j, sy, sx, u1, u2);
+                        rays[p] = ray.ox; rays[n + p] = ray.oy; rays[2 * n + p] = ray.oz;   // SoA: :65-71
+                        rays[3 * n + p] = ray.dx; rays[4 * n + p] = ray.dy; rays[5 * n + p] = ray.dz;
                     }
     return APT_OK;
 }

@@ -360,8 +360,12 @@ APT_HD double tent(double u) { // gen_data.py:37-40
     return (r < 1) ? sqrt(r) - 1 : 1 - sqrt(2 - r);
 }
 
+struct Ray { float ox, oy, oz, dx, dy, dz; };
+
+// Outputs are six scalar references on purpose: an aggregate result gets its stores merged into
+// vector stores to a stack slot that SROA can then no longer promote (it ended up in scratch).
 APT_HD void camera_ray(const Camera &c, uint32_t w, uint32_t h, uint32_t i, uint32_t j, uint32_t sy, uint32_t sx,
-                       double u1, double u2, float ray[6]) {
+                       double u1, double u2, float &rox, float &roy, float &roz, float &rdx, float &rdy, float &rdz) {
     double ddx = tent(u1), ddy = tent(u2);
     double a = (((double)sx + 0.5 + ddx) / 2 + (double)i) / (double)w - 0.5; // :41
     double b = (((double)sy + 0.5 + ddy) / 2 + (double)j) / (double)h - 0.5; // :42
@@ -369,12 +373,18 @@ APT_HD void camera_ray(const Camera &c, uint32_t w, uint32_t h, uint32_t i, uint
     double d1 = (c.cx[1] * a + c.cy[1] * b) + c.g[1];
     double d2 = (c.cx[2] * a + c.cy[2] * b) + c.g[2];
     double n = norm3(d0, d1, d2);
-    ray[0] = (float)(c.pos[0] + d0 * 140);                                   // :45
-    ray[1] = (float)(c.pos[1] + d1 * 140);
-    ray[2] = (float)(c.pos[2] + d2 * 140);
-    ray[3] = (float)(d0 / n);                                                // :46
-    ray[4] = (float)(d1 / n);
-    ray[5] = (float)(d2 / n);
+    rox = (float)(c.pos[0] + d0 * 140);                                      // :45
+    roy = (float)(c.pos[1] + d1 * 140);
+    roz = (float)(c.pos[2] + d2 * 140);
+    rdx = (float)(d0 / n);                                                   // :46
+    rdy = (float)(d1 / n);
+    rdz = (float)(d2 / n);
+}
+APT_HD Ray camera_ray(const Camera &c, uint32_t w, uint32_t h, uint32_t i, uint32_t j, uint32_t sy, uint32_t sx,
+                      double u1, double u2) {
+    Ray r;
+    camera_ray(c, w, h, i, j, sy, sx, u1, u2, r.ox, r.oy, r.oz, r.dx, r.dy, r.dz);
+    return r;
 }
 
 // Counter-based generator for on-device ray generation: splitmix64 of (seed, path index)

@@ -76,11 +76,12 @@ struct LeafProg { // numpy pairwise_sum recursion flattened (see build_leaves)
 // ops round exactly like the scalar ones, element by element; contraction is off.
 typedef float f2 __attribute__((ext_vector_type(2)));
 struct HitPre2 { f2 b, disc; };
-__device__ __forceinline__ HitPre2 intersect_pre2(const f2 cx, const f2 cy, const f2 cz, const f2 r2, const PathState &s) {
-    const f2 ocx = cx - s.ox, ocy = cy - s.oy, ocz = cz - s.oz;
-    f2 b = ocx * s.dx;
-    b = b + ocy * s.dy;
-    b = b + ocz * s.dz;
+__device__ __forceinline__ HitPre2 intersect_pre2(const f2 cx, const f2 cy, const f2 cz, const f2 r2, float ox,
+                                                  float oy, float oz, float dx, float dy, float dz) {
+    const f2 ocx = cx - ox, ocy = cy - oy, ocz = cz - oz;
+    f2 b = ocx * dx;
+    b = b + ocy * dy;
+    b = b + ocz * dz;
     f2 c = ocx * ocx;
     c = c + ocy * ocy;
     c = c + ocz * ocz;
@@ -89,8 +90,9 @@ __device__ __forceinline__ HitPre2 intersect_pre2(const f2 cx, const f2 cy, cons
     disc = disc - c;
     return {b, disc};
 }
-__device__ __forceinline__ HitPre2 intersect_pre2(const float4 a, const float4 c4, const PathState &s) {
-    return intersect_pre2(f2{a.x, a.y}, f2{a.z, a.w}, f2{c4.x, c4.y}, f2{c4.z, c4.w}, s);
+__device__ __forceinline__ HitPre2 intersect_pre2(const float4 a, const float4 c4, float ox, float oy, float oz,
+                                                  float dx, float dy, float dz) {
+    return intersect_pre2(f2{a.x, a.y}, f2{a.z, a.w}, f2{c4.x, c4.y}, f2{c4.z, c4.w}, ox, oy, oz, dx, dy, dz);
 }
 
 
@@ -110,7 +112,8 @@ __device__ __forceinline__ bool bounce_ns8(const Scene8 &sc, const float4 *tab, 
 #pragma unroll
         for (int k = 0; k < 8; k += 2) { // rt_helper.h:457-467, two spheres per packed instruction
             const HitPre2 h = intersect_pre2(f2{sc.cx[k], sc.cx[k + 1]}, f2{sc.cy[k], sc.cy[k + 1]},
-                                             f2{sc.cz[k], sc.cz[k + 1]}, f2{sc.r2[k], sc.r2[k + 1]}, s);
+                                             f2{sc.cz[k], sc.cz[k + 1]}, f2{sc.r2[k], sc.r2[k + 1]}, s.ox, s.oy, s.oz,
+                                             s.dx, s.dy, s.dz);
             // sqrt_rn_rsq1 on both lanes of the pair (pt_core.h): y = x*r, hh = r/2, q = fma(fma(-y,y,x), hh, y)
             amin = fminf(amin, fminf(fabsf(h.disc.x), fabsf(h.disc.y)));
             const f2 r0 = {__builtin_amdgcn_rsqf(h.disc.x), __builtin_amdgcn_rsqf(h.disc.y)};
@@ -219,7 +222,8 @@ __device__ __forceinline__ uint32_t trace_dyn(const float *__restrict__ sph, flo
             };
             for (uint32_t k = 0; k < n; k += 4) {
                 const float4 a0 = tile[k], c0 = tile[k + 1], a1 = tile[k + 2], c1 = tile[k + 3];
-                const HitPre2 h01 = intersect_pre2(a0, c0, s), h23 = intersect_pre2(a1, c1, s);
+                const HitPre2 h01 = intersect_pre2(a0, c0, s.ox, s.oy, s.oz, s.dx, s.dy, s.dz);
+                const HitPre2 h23 = intersect_pre2(a1, c1, s.ox, s.oy, s.oz, s.dx, s.dy, s.dz);
                 const float m = fmaxf(fmaxf(h01.disc.x, h01.disc.y), fmaxf(h23.disc.x, h23.disc.y)); // NaNs drop out
                 if (__any(m >= 0.0f)) {
                     hit(h01.b.x, h01.disc.x, base + k);
@@ -300,7 +304,7 @@ struct FrameArgs {
 // a 3-step butterfly and no shared memory.  GROUP == 1 serves samples < 8 (numpy sums
 // those sequentially).
 template <int MODE, bool NS8, int GROUP, bool RETIRE>
-__global__ __launch_bounds__(kBlock) void render_frame_kernel(const float *__restrict__ sph, FrameArgs fa,
+__global__ __launch_bounds__(kBlock, (RETIRE && NS8 && GROUP == 8) ? 5 : 1) void render_frame_kernel(const float *__restrict__ sph, FrameArgs fa,
                                                               TraceArgs ta, LeafProg lp) {
     __shared__ float4 tab[16];
     __shared__ float4 tile[NS8 ? 1 : kTile];
@@ -327,30 +331,30 @@ __global__ __launch_bounds__(kBlock) void render_frame_kernel(const float *__res
     const uint64_t pbase = (q * 4 + sub) * fa.samples;
     uint32_t traced = 0;
 
-    auto sample = [&](uint32_t k, float c[3]) {
+    struct Col { float r, g, b; };
+    auto sample = [&](uint32_t k) -> Col {
         double u1, u2;
         path_uniforms(fa.seed, pbase + k, u1, u2);
-        float ray[6];
-        camera_ray(cam, fa.width, fa.height, pi, pj, sy, sx, u1, u2, ray);
+        float rox, roy, roz, rdx, rdy, rdz;
+        camera_ray(cam, fa.width, fa.height, pi, pj, sy, sx, u1, u2, rox, roy, roz, rdx, rdy, rdz);
         PathState s;
-        path_init(s, ray[0], ray[1], ray[2], ray[3], ray[4], ray[5]);
+        path_init(s, rox, roy, roz, rdx, rdy, rdz);
         traced += NS8 ? trace_ns8<MODE, RETIRE>(sc, tab, s, valid, ta)
                       : trace_dyn<MODE, RETIRE>(sph, tile, s, valid, ta);
-        c[0] = s.rx * ta.gain; c[1] = s.ry * ta.gain; c[2] = s.rz * ta.gain;
+        return Col{s.rx * ta.gain, s.ry * ta.gain, s.rz * ta.gain};
     };
+    auto add = [](const Col &a, const Col &b) { return Col{a.r + b.r, a.g + b.g, a.b + b.b}; };
 
     float res[3] = {0.0f, 0.0f, 0.0f};
     uint32_t start = 0;
     int sp = 0;
     for (uint32_t leaf = 0; leaf < lp.nleaves; ++leaf) {
         const uint32_t n = lp.len(leaf);
-        float acc[3], c[3];
+        float acc[3];
         if (GROUP == 1) { // n < 8: res = 0; res += a[i]
-            acc[0] = acc[1] = acc[2] = 0.0f;
-            for (uint32_t k = 0; k < n; ++k) {
-                sample(start + k, c);
-                acc[0] = acc[0] + c[0]; acc[1] = acc[1] + c[1]; acc[2] = acc[2] + c[2];
-            }
+            Col a = {0.0f, 0.0f, 0.0f};
+            for (uint32_t k = 0; k < n; ++k) a = add(a, sample(start + k));
+            acc[0] = a.r; acc[1] = a.g; acc[2] = a.b;
         } else {          // 8 <= n <= 128: r[j] chains, tree, tail
             const uint32_t nfull = n & ~7u;
             if (RETIRE && NS8) {
@@ -369,7 +373,7 @@ __global__ __launch_bounds__(kBlock) void render_frame_kernel(const float *__res
                 uint32_t next = 0;                        // first unissued item (uniform)
                 uint32_t depth_left = 0, cur_item = 0, slot_item = 0;
                 uint32_t n_bounce_exec = 0, n_gen_exec = 0; // wave-level executions (statistics only)
-                float slot[6];
+                float sl_ox = 0.f, sl_oy = 0.f, sl_oz = 0.f, sl_dx = 0.f, sl_dy = 0.f, sl_dz = 1.f; // the one-ray slot
                 bool slot_full = false, slot_valid = false, cur_valid = false;
                 PathState s;
                 path_init(s, 0.f, 0.f, 0.f, 0.f, 0.f, 1.f);
@@ -397,14 +401,15 @@ __global__ __launch_bounds__(kBlock) void render_frame_kernel(const float *__res
                             slot_valid = gvalid;
                             double u1, u2;
                             path_uniforms(fa.seed, (((uint64_t)bhi << 32) | blo) + start + k, u1, u2);
-                            camera_ray(cam, fa.width, fa.height, gpi, gpj, gsub >> 1, gsub & 1u, u1, u2, slot);
+                            camera_ray(cam, fa.width, fa.height, gpi, gpj, gsub >> 1, gsub & 1u, u1, u2, sl_ox, sl_oy, sl_oz, sl_dx,
+                                       sl_dy, sl_dz);
                             slot_item = item;
                             slot_full = true;
                         }
                         next += min((uint32_t)__popcll(wants), remaining);
                     }
                     if (depth_left == 0 && slot_full) { // start the waiting ray
-                        path_init(s, slot[0], slot[1], slot[2], slot[3], slot[4], slot[5]);
+                        path_init(s, sl_ox, sl_oy, sl_oz, sl_dx, sl_dy, sl_dz);
                         cur_item = slot_item;
                         cur_valid = slot_valid;
                         depth_left = ta.depth;
@@ -455,11 +460,9 @@ __global__ __launch_bounds__(kBlock) void render_frame_kernel(const float *__res
                     atomicAdd(ta.traced + 2, 64ull * n_gen_exec);
                 }
             } else {
-                sample(start + j, acc);
-                for (uint32_t i8 = 8; i8 < nfull; i8 += 8) {
-                    sample(start + i8 + j, c);
-                    acc[0] = acc[0] + c[0]; acc[1] = acc[1] + c[1]; acc[2] = acc[2] + c[2];
-                }
+                Col a = sample(start + j);
+                for (uint32_t i8 = 8; i8 < nfull; i8 += 8) a = add(a, sample(start + i8 + j));
+                acc[0] = a.r; acc[1] = a.g; acc[2] = a.b;
             }
 #pragma unroll
             for (int ch = 0; ch < 3; ++ch) { // ((r0+r1)+(r2+r3)) + ((r4+r5)+(r6+r7))
@@ -471,10 +474,12 @@ __global__ __launch_bounds__(kBlock) void render_frame_kernel(const float *__res
             }
             const uint32_t nt = n - nfull;
             if (nt) { // res += a[i] for the n % 8 trailing samples, in order
-                sample(start + nfull + (j < nt ? j : 0), c);
+                const Col c = sample(start + nfull + (j < nt ? j : 0));
                 for (uint32_t t = 0; t < nt; ++t) {
-#pragma unroll
-                    for (int ch = 0; ch < 3; ++ch) acc[ch] = acc[ch] + __shfl(c[ch], (int)((lane & ~7u) + t), 64);
+                    const int src = (int)((lane & ~7u) + t);
+                    acc[0] = acc[0] + __shfl(c.r, src, 64);
+                    acc[1] = acc[1] + __shfl(c.g, src, 64);
+                    acc[2] = acc[2] + __shfl(c.b, src, 64);
                 }
             }
         }
@@ -554,10 +559,10 @@ __global__ __launch_bounds__(kBlock) void gen_rays_kernel(Camera cam, uint32_t w
     path_coords(p, height, samples, i, j, sy, sx);
     double u1, u2;
     path_uniforms(seed, p, u1, u2);
-    float ray[6];
-    camera_ray(cam, width, height, i, j, sy, sx, u1, u2, ray);
-#pragma unroll
-    for (int m = 0; m < 6; ++m) rays[(uint64_t)m * n_total + p] = ray[m];
+    float rox, roy, roz, rdx, rdy, rdz;
+    camera_ray(cam, width, height, i, j, sy, sx, u1, u2, rox, roy, roz, rdx, rdy, rdz);
+    rays[p] = rox; rays[n_total + p] = roy; rays[2 * n_total + p] = roz;
+    rays[3 * n_total + p] = rdx; rays[4 * n_total + p] = rdy; rays[5 * n_total + p] = rdz;
 }
 
 // ---- kernel: device decode_color -----------------------------------------------------------
