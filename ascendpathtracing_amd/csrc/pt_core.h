@@ -135,14 +135,19 @@ __device__ __forceinline__ float sqrt_rn_rsq2(float x, float &amin) {
 // When neither operand needs scaling (no operand or quotient near the ends of the exponent
 // range, numerator non-zero) div_scale and div_fixup are identities and div_fmas is a plain FMA,
 // so the reciprocal refinement can be shared by the three numerators: 1 rcp + 2 + 3*5 ops instead
-// of 3*11.  `ok` is cleared when any |operand| is outside [2^-40, 2^40] (or NaN); the caller then
-// redoes the bounce with the plain `/`.  apt_selftest_div3 compares it with `/` on 2^32
-// structured + random operand sets.
-__device__ __forceinline__ void div3_shared(float nx, float ny, float nz, float d, float &ux, float &uy, float &uz,
-                                            bool &ok) {
-    const float lo = fminf(fminf(fabsf(nx), fabsf(ny)), fminf(fabsf(nz), fabsf(d)));
-    const float hi = fmaxf(fmaxf(fabsf(nx), fabsf(ny)), fmaxf(fabsf(nz), fabsf(d)));
-    ok = ok && (lo >= 0x1p-40f) && (hi <= 0x1p40f);
+// of 3*11.  The caller redoes the bounce with the plain `/` when the validity flags say so.
+// apt_selftest_div3 compares it with `/` on 2^32 structured + random operand sets.
+__device__ __forceinline__ void div3_shared(float nx, float ny, float nz, float d, float len2, float &ux, float &uy,
+                                            float &uz, float &amin, uint32_t &hiflag) {
+    // Validity of the unscaled sequence: numerators not -0 and >= 2^-96 in magnitude (v_div_scale
+    // leaves |num| >= 2^-103 alone, and the quotient must stay normal), the divisor d = sqrt(len2)
+    // <= 2^30.  The first folds into the sqrt sequences' running minimum `amin` (same threshold
+    // 2^-96; +-0 is flagged too, which only costs an exact re-run); the second is the sign bit of
+    // bits(2^60) - bits(len2) (len2 >= 0 or NaN), OR-ed into `hiflag` with 2-cycle integer ops.
+    // len2 itself must not have underflowed (d would be 0 or unrelated to the numerators).
+    amin = fminf(fminf(amin, fabsf(nx)), fminf(fabsf(ny), fabsf(nz)));
+    amin = fminf(amin, len2);
+    hiflag |= 0x5d800000u - __float_as_uint(len2);
     const float r0 = __builtin_amdgcn_rcpf(d);
     const float e0 = __builtin_fmaf(-d, r0, 1.0f);
     const float r = __builtin_fmaf(e0, r0, r0);
@@ -225,8 +230,13 @@ APT_HD void rootkey_init(RootKey &k, float eps, int miss_idx) {
 }
 APT_HD void rootkey_update(RootKey &k, float t0, float t1, int sphere) {
     const uint32_t m0 = f32_bits(t0) - k.bias, m1 = f32_bits(t1) - k.bias;
+    uint32_t nb;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm("v_min3_u32 %0, %1, %2, %3" : "=v"(nb) : "v"(k.best), "v"(m0), "v"(m1)); // one 4-cycle op instead of two
+#else
     const uint32_t m = m0 < m1 ? m0 : m1;
-    const uint32_t nb = m < k.best ? m : k.best;
+    nb = m < k.best ? m : k.best;
+#endif
     k.idx = (nb != k.best) ? sphere : k.idx;
     k.best = nb;
 }
@@ -272,6 +282,7 @@ APT_HD void shade_and_reflect(PathState &s, float tmin, float cx, float cy, floa
         acc = acc + nz * nz;
         L = acc;
     }
+    const float len2 = L; (void)len2;
 #if defined(__HIP_DEVICE_COMPILE__)
     if (FAST) L = sqrt_rn_core(L, *amin);
     else
@@ -280,9 +291,9 @@ APT_HD void shade_and_reflect(PathState &s, float tmin, float cx, float cy, floa
     float ux, uy, uz;                                           // :664-666 IEEE divide
 #if defined(__HIP_DEVICE_COMPILE__)
     if (FAST) {
-        bool ok = true;
-        div3_shared(nx, ny, nz, L, ux, uy, uz, ok);
-        if (!ok) *amin = 0.0f;                                  // forces the exact re-run of this bounce
+        uint32_t hiflag = 0;
+        div3_shared(nx, ny, nz, L, len2, ux, uy, uz, *amin, hiflag);
+        if ((int32_t)hiflag < 0) *amin = 0.0f;                  // forces the exact re-run of this bounce
     } else
 #endif
     {

@@ -645,10 +645,11 @@ __global__ __launch_bounds__(kBlock) void selftest_sqrt_kernel(int variant, uint
 }
 
 // ---- kernel: self-test of the shared-reciprocal divide --------------------------------------
-// Operand set i of [begin, begin+count): three numerators and one divisor built from a counter
-// hash; a quarter of the sets use special mantissas (all ones, 1.0, powers of two, one-bit
-// neighbours) and exponents at the edges of the accepted range.  Every accepted set must give
-// the three quotients of the plain `/` bit for bit.
+// Operand set i of [begin, begin+count): three numerators built from a counter hash, the divisor
+// formed from them exactly as the shading step does (sqrt of the sum of squares); a quarter of the
+// sets use special mantissas (all ones, 1.0, powers of two, one-bit neighbours), exponents at the
+// edges of the accepted range and signed zeros.  Every set the validity flags accept must give the
+// three quotients of the plain `/` bit for bit.
 __global__ __launch_bounds__(kBlock) void selftest_div3_kernel(uint64_t begin, uint64_t count,
                                                                unsigned long long *result) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -656,25 +657,32 @@ __global__ __launch_bounds__(kBlock) void selftest_div3_kernel(uint64_t begin, u
     unsigned long long bad = 0, first = ~0ull, accepted = 0;
     for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < count; i += stride) {
         uint64_t h = splitmix64(begin + i);
-        float v[4];
+        float v[3];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < 3; ++k) {
             h = splitmix64(h);
-            uint32_t man = (uint32_t)h & 0x7fffffu, ex = 127u - 44u + (uint32_t)((h >> 23) % 89u), sg = (uint32_t)(h >> 63);
+            // exponents over the whole accepted range and a little beyond it on both sides
+            uint32_t man = (uint32_t)h & 0x7fffffu, ex = 127u - 100u + (uint32_t)((h >> 23) % 134u), sg = (uint32_t)(h >> 63);
             if (((begin + i) & 3u) == 0u) {
                 const uint32_t pick = (uint32_t)(h >> 40) & 7u;
                 man = pick == 0 ? 0x7fffffu : pick == 1 ? 0u : pick == 2 ? 1u : pick == 3 ? 0x7ffffeu
                     : pick == 4 ? 0x400000u : pick == 5 ? 0x3fffffu : pick == 6 ? 0x400001u : man;
-                if (((h >> 44) & 3u) == 0u) ex = ((h >> 46) & 1u) ? 127u - 40u : 127u + 39u;
+                if (((h >> 44) & 3u) == 0u) ex = ((h >> 46) & 1u) ? 127u - 96u : 127u + 29u;
             }
             v[k] = __uint_as_float((sg << 31) | (ex << 23) | man);
         }
-        float ux, uy, uz;
-        bool ok = true;
-        div3_shared(v[0], v[1], v[2], v[3], ux, uy, uz, ok);
-        if (!ok) continue;
+        if (((begin + i) & 63u) == 1u) v[((begin + i) >> 6) % 3u] = ((begin + i) & 64u) ? 0.0f : -0.0f; // zero numerators
+        // the divisor exactly as the shading step forms it (K-mode order; O-mode differs by one rounding)
+        float len2 = 0.0f + v[0] * v[0];
+        len2 = len2 + v[1] * v[1];
+        len2 = len2 + v[2] * v[2];
+        const float d = sqrtf(len2);
+        float ux, uy, uz, amin = 1.0f;
+        uint32_t hiflag = 0;
+        div3_shared(v[0], v[1], v[2], d, len2, ux, uy, uz, amin, hiflag);
+        if (amin < 0x1p-96f || (int32_t)hiflag < 0) continue; // the kernel redoes these with '/'
         ++accepted;
-        const float wx = v[0] / v[3], wy = v[1] / v[3], wz = v[2] / v[3];
+        const float wx = v[0] / d, wy = v[1] / d, wz = v[2] / d;
         if (__float_as_uint(ux) != __float_as_uint(wx) || __float_as_uint(uy) != __float_as_uint(wy) ||
             __float_as_uint(uz) != __float_as_uint(wz)) { ++bad; if (first == ~0ull) first = begin + i; }
     }
