@@ -64,6 +64,21 @@ KERNEL(k_fmac, "v_fmac_f32 %0, %1, %2\n")
 KERNEL(k_mul_f32_sgpr, "v_mul_f32 %0, %14, %2\n")
 KERNEL(k_add_4indep, "v_add_f32 %0, %1, %2\nv_add_f32 %3, %4, %5\nv_add_f32 %6, %7, %1\nv_add_f32 %4, %2, %5\n")
 KERNEL(k_pk_4indep, "v_pk_add_f32 %8, %9, %10\nv_pk_mul_f32 %11, %9, %10\n")
+KERNEL(k_mul_lo_u32, "v_mul_lo_u32 %12, %13, %12\n")
+KERNEL(k_mul_hi_u32, "v_mul_hi_u32 %12, %13, %12\n")
+KERNEL(k_mad_u64_u32, "v_mad_u64_u32 %8, vcc, %12, %13, %9\n")
+KERNEL(k_lshr_b64, "v_lshrrev_b64 %8, 7, %9\n")
+KERNEL(k_xor, "v_xor_b32 %12, %13, %12\n")
+KERNEL(k_rsq_f64, "v_rsq_f64 %8, %9\n")
+KERNEL(k_rcp_f64, "v_rcp_f64 %8, %9\n")
+KERNEL(k_sqrt_f64, "v_sqrt_f64 %8, %9\n")
+KERNEL(k_div_scale_f64, "v_div_scale_f64 %8, vcc, %9, %10, %9\n")
+KERNEL(k_div_fmas_f64, "v_div_fmas_f64 %8, %9, %10, %11\n")
+KERNEL(k_div_fixup_f64, "v_div_fixup_f64 %8, %9, %10, %11\n")
+KERNEL(k_ldexp_f64, "v_ldexp_f64 %8, %9, %12\n")
+KERNEL(k_cvt_f64_u32, "v_cvt_f64_u32 %8, %12\n")
+KERNEL(k_cmp_f64, "v_cmp_lt_f64 vcc, %8, %9\n")
+KERNEL(k_mul_u32_u24, "v_mul_u32_u24 %12, %13, %12\n")
 KERNEL(k_readlane_like_dpp, "v_mov_b32_dpp %0, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n")
 
 typedef void (*kfn)(float *, int, float, float);
@@ -80,7 +95,10 @@ int main() {
         {"v_min_f32", k_min, 1}, {"v_min3_f32", k_min3, 1}, {"v_med3_f32", k_med3, 1}, {"v_sub_f32 |abs| e64", k_sub_abs, 1},
         {"v_add_f64", k_add_f64, 1}, {"v_mul_f64", k_mul_f64, 1}, {"v_fma_f64", k_fma_f64, 1}, {"v_cvt_f64_f32", k_cvt_f64_f32, 1}, {"v_cvt_f32_f64", k_cvt_f32_f64, 1},
         {"v_div_scale_f32", k_div_scale, 1}, {"v_div_fmas_f32", k_div_fmas, 1}, {"v_div_fixup_f32", k_div_fixup, 1},
-        {"v_add+v_mul alternating", k_mix_add_mul, 2}, {"v_pk_add_f32 (sgpr pair)", k_pk_add_sgpr, 1}, {"v_pk_add_f32 (sgpr pair, neg)", k_pk_add_sgpr_neg, 1},
+        {"v_add+v_mul alternating", k_mix_add_mul, 2}, {"v_mul_lo_u32", k_mul_lo_u32, 1}, {"v_mul_hi_u32", k_mul_hi_u32, 1}, {"v_mad_u64_u32", k_mad_u64_u32, 1},
+        {"v_mul_u32_u24", k_mul_u32_u24, 1}, {"v_lshrrev_b64", k_lshr_b64, 1}, {"v_xor_b32", k_xor, 1}, {"v_rsq_f64", k_rsq_f64, 1}, {"v_rcp_f64", k_rcp_f64, 1}, {"v_sqrt_f64", k_sqrt_f64, 1},
+        {"v_div_scale_f64", k_div_scale_f64, 1}, {"v_div_fmas_f64", k_div_fmas_f64, 1}, {"v_div_fixup_f64", k_div_fixup_f64, 1}, {"v_ldexp_f64", k_ldexp_f64, 1},
+        {"v_cvt_f64_u32", k_cvt_f64_u32, 1}, {"v_cmp_lt_f64", k_cmp_f64, 1}, {"v_pk_add_f32 (sgpr pair)", k_pk_add_sgpr, 1}, {"v_pk_add_f32 (sgpr pair, neg)", k_pk_add_sgpr_neg, 1},
         {"v_pk_mul_f32 op_sel_hi", k_pk_mul_opsel, 1}, {"v_min_u32", k_min_u32, 1}, {"v_min3_u32", k_min3_u32, 1}, {"v_subrev_u32", k_subrev_u32, 1},
         {"v_cmp_le_u32 (vcc)", k_cmp_u32, 1}, {"v_pk_mov_b32", k_pk_mov, 1}, {"v_fmac_f32", k_fmac, 1}, {"v_mul_f32 (sgpr src)", k_mul_f32_sgpr, 1},
         {"4 independent v_add_f32", k_add_4indep, 4}, {"v_pk_add + v_pk_mul (different dst)", k_pk_4indep, 2}, {"s_nop 0", k_nop, 1}};
