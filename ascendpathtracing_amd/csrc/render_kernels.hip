@@ -165,6 +165,7 @@ __device__ __forceinline__ uint32_t trace_ns8(const Scene8 &sc, const float4 *ta
             if (__any(redo)) {
                 asm volatile("" ::: "memory");
                 (void)bounce_ns8<MODE, false>(sc, tab, s, n, ta);
+                if (ta.traced && (threadIdx.x & 63) == 0) atomicAdd(ta.traced + 3, 1ull); // statistics: exact re-runs
             }
         }
         if (RETIRE) {
@@ -432,16 +433,16 @@ __global__ __launch_bounds__(kBlock, (RETIRE && NS8 && GROUP == 8) ? 5 : 1) void
                         asm volatile("" ::: "memory");
                         (void)bounce_ns8<MODE, false>(sc, tab, s, nx, ta);
                     }
-                    if (active) {
-                        s = nx;
-                        ++traced;
-                        --depth_left;
-                        if (depth_left == 0 || path_finished(s)) {
-                            depth_left = 0;
-                            colq[cur_item] = s.rx * ta.gain;
-                            colq[qstride + cur_item] = s.ry * ta.gain;
-                            colq[2 * qstride + cur_item] = s.rz * ta.gain;
-                        }
+                    // inactive lanes computed on stale state; whatever they hold is overwritten when
+                    // they start their next ray, so the update itself needs no mask
+                    s = nx;
+                    traced += active ? 1u : 0u;
+                    depth_left -= active ? 1u : 0u;
+                    if (active && (depth_left == 0 || path_finished(s))) {
+                        depth_left = 0;
+                        colq[cur_item] = s.rx * ta.gain;
+                        colq[qstride + cur_item] = s.ry * ta.gain;
+                        colq[2 * qstride + cur_item] = s.rz * ta.gain;
                     }
                 }
                 __syncthreads(); // colours of the whole leaf are in LDS (only wave-local data is read back)

@@ -126,6 +126,11 @@ class TraceCounter:
         the last two only from the refill loop of render_frame with APT_FLAG_RETIRE."""
         return tuple(int(x) for x in self.buf[:3].tolist())
 
+    @property
+    def exact_reruns(self):
+        """Wave-level exact re-runs of a bounce (fast sqrt/divide sequences outside their validity range)."""
+        return int(self.buf[3].item())
+
 
 def selftest_sqrt(variant=0, first_bits=0, count=1 << 32, stream=None):
     """Exhaustive check of the hot loop's fast sqrt against sqrtf(): -> (mismatches, first bad bits)."""

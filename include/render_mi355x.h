@@ -158,7 +158,8 @@ int apt_write_ppm(const char *path, uint32_t width, uint32_t height, const uint8
 /* ---- diagnostics ------------------------------------------------------------------- */
 /* Optional DEVICE uint64[4] statistics block.  [0] += ray segments actually traced by every
  * render launch (== paths*depth unless APT_FLAG_RETIRE); [1], [2] += lane-slots (64 per wave-level
- * execution) spent in bounce / ray-generate by the refill loop of render_frame.  NULL disables it.
+ * execution) spent in bounce / ray-generate by the refill loop of render_frame; [3] += wave-level
+ * exact re-runs of a bounce (full-trace Ns = 8 loop).  NULL disables it.
  * The caller zeroes it; process-wide. */
 int apt_set_trace_counter(uint64_t *device_counter);
 
