@@ -31,14 +31,18 @@ class FrameShard:
         uint8   [max_count][3]  8-bit pixels
     """
 
-    def __init__(self, params: RenderParams, rank=0, world=1, device=None):
-        self.params, self.rank, self.world = params, rank, world
+    def __init__(self, params: RenderParams, rank=0, world=1, device=None, slots=1):
+        """slots > 1 allocates that many packed buffers so that the gather of one frame can overlap
+        the render of the next (see gather_async)."""
+        self.params, self.rank, self.world, self.slots = params, rank, world, max(1, slots)
         self.npix = params.width * params.height
         self.pixel_begin, self.pixel_count = split_range(self.npix, rank, world)
         self.max_count = split_range(self.npix, 0, world)[1]
         self.device = device if device is not None else ("cuda" if torch.cuda.is_available() else "cpu")
         self._packed = None
         self._gather_list = None
+        self._slot_bufs = []
+        self._pending = None
 
     @property
     def packed_bytes(self):
@@ -93,6 +97,50 @@ class FrameShard:
                 full_u8[b:b + c] = buf[12 * self.max_count:].view(self.max_count, 3)[:c]
         else:
             dist.gather(self._packed, None, dst=dst)
+
+
+    # ---- pipelined form: the gather of frame k overlaps the render of frame k+1 -------------------
+    def alloc_slots(self):
+        """-> list of (fb, u8) view pairs, one per slot (requires equal shards: pixel_count == max_count)."""
+        if self.pixel_count != self.max_count:
+            raise ValueError("pipelined gather needs equal shards")
+        self._slot_bufs = [torch.zeros(self.packed_bytes, dtype=torch.uint8, device=self.device) for _ in range(self.slots)]
+        if self.rank == 0:
+            self._slot_lists = [[torch.empty_like(self._slot_bufs[0]) for _ in range(self.world)] for _ in range(self.slots)]
+        return [(b[:12 * self.max_count].view(torch.float32).view(3, self.max_count),
+                 b[12 * self.max_count:].view(self.max_count, 3)) for b in self._slot_bufs]
+
+    def gather_async(self, slot, full_fb=None, full_u8=None, dst=0):
+        """Enqueue the gather of slot `slot` (asynchronously: the collective runs on the backend's own
+        stream after the work already queued on the current stream) and finish the previous one."""
+        self.finish()
+        if self.world == 1 and not dist.is_initialized():
+            self._pending = ("local", slot, full_fb, full_u8)
+            return
+        if self.rank == dst:
+            work = dist.gather(self._slot_bufs[slot], self._slot_lists[slot], dst=dst, async_op=True)
+        else:
+            work = dist.gather(self._slot_bufs[slot], None, dst=dst, async_op=True)
+        self._pending = (work, slot, full_fb, full_u8)
+
+    def finish(self):
+        """Wait for the pending gather (if any) and, on the root, scatter the slices into the frame."""
+        if self._pending is None:
+            return
+        work, slot, full_fb, full_u8 = self._pending
+        self._pending = None
+        if work == "local":
+            bufs = [self._slot_bufs[slot]]
+        else:
+            work.wait()
+            if self.rank != 0:
+                return
+            bufs = self._slot_lists[slot]
+        if full_fb is not None:
+            for r, buf in enumerate(bufs):
+                b, c = split_range(self.npix, r, self.world)
+                full_fb[:, b:b + c] = buf[:12 * self.max_count].view(torch.float32).view(3, self.max_count)[:, :c]
+                full_u8[b:b + c] = buf[12 * self.max_count:].view(self.max_count, 3)[:c]
 
 
 def render_frame_sharded(params: RenderParams, spheres, rank=None, world=None, render_fn=None, device=None):
