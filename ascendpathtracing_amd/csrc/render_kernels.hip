@@ -109,6 +109,15 @@ __device__ __forceinline__ bool bounce_ns8(const Scene8 &sc, const float4 *tab, 
     if (FAST) {
         RootKey key;
         rootkey_init(key, ta.eps, miss);
+#if defined(APT_NS8_SCALAR) // A/B switch: one sphere per scalar instruction stream
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            float t0, t1;
+            intersect_roots<true>(sc.cx[k], sc.cy[k], sc.cz[k], sc.r2[k], s.ox, s.oy, s.oz, s.dx, s.dy, s.dz, t0, t1,
+                                  amin);
+            rootkey_update(key, t0, t1, k);
+        }
+#else
 #pragma unroll
         for (int k = 0; k < 8; k += 2) { // rt_helper.h:457-467, two spheres per packed instruction
             const HitPre2 h = intersect_pre2(f2{sc.cx[k], sc.cx[k + 1]}, f2{sc.cy[k], sc.cy[k + 1]},
@@ -124,6 +133,7 @@ __device__ __forceinline__ bool bounce_ns8(const Scene8 &sc, const float4 *tab, 
             rootkey_update(key, t0.x, t1.x, k);
             rootkey_update(key, t0.y, t1.y, k + 1);
         }
+#endif
         tmin = rootkey_tmin(key);
         idx = key.idx;
     } else {

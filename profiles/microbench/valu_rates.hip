@@ -79,6 +79,19 @@ KERNEL(k_ldexp_f64, "v_ldexp_f64 %8, %9, %12\n")
 KERNEL(k_cvt_f64_u32, "v_cvt_f64_u32 %8, %12\n")
 KERNEL(k_cmp_f64, "v_cmp_lt_f64 vcc, %8, %9\n")
 KERNEL(k_mul_u32_u24, "v_mul_u32_u24 %12, %13, %12\n")
+KERNEL(k_rsq_3add, "v_rsq_f32 %0, %1\nv_add_f32 %2, %3, %4\nv_add_f32 %5, %6, %7\nv_add_f32 %3, %4, %6\n")
+KERNEL(k_rsq_6add, "v_rsq_f32 %0, %1\nv_add_f32 %2, %3, %4\nv_add_f32 %5, %6, %7\nv_add_f32 %3, %4, %6\nv_add_f32 %2, %3, %4\nv_add_f32 %5, %6, %7\nv_add_f32 %3, %4, %6\n")
+KERNEL(k_rsq_2pk, "v_rsq_f32 %0, %1\nv_pk_add_f32 %8, %9, %10\nv_pk_mul_f32 %11, %9, %10\n")
+KERNEL(k_cmp_add, "v_cmp_lt_f32 vcc, %1, %2\nv_add_f32 %3, %4, %5\n")
+KERNEL(k_pk_1add, "v_pk_add_f32 %8, %9, %10\nv_add_f32 %0, %1, %2\n")
+KERNEL(k_pk_2add, "v_pk_mul_f32 %8, %9, %10\nv_add_f32 %0, %1, %2\nv_mul_f32 %3, %4, %5\n")
+KERNEL(k_cnd_add, "v_cndmask_b32 %0, %1, %2, vcc\nv_add_f32 %3, %4, %5\n")
+KERNEL(k_min_add, "v_min3_u32 %12, %13, %12, %13\nv_add_f32 %3, %4, %5\n")
+KERNEL(k_f64_add, "v_fma_f64 %8, %9, %10, %11\nv_add_f32 %3, %4, %5\n")
+KERNEL(k_sgpr_add, "v_add_f32 %0, %14, %2\nv_add_f32 %3, %4, %5\n")
+KERNEL(k_pk_pk_add_add, "v_pk_add_f32 %8, %9, %10\nv_pk_mul_f32 %11, %9, %10\nv_add_f32 %0, %1, %2\nv_mul_f32 %3, %4, %5\n")
+KERNEL(k_rsq_indep, "v_rsq_f32 %0, %1\nv_add_f32 %2, %3, %4\nv_add_f32 %5, %3, %4\nv_add_f32 %6, %3, %4\n")
+KERNEL(k_rsq_cmp, "v_rsq_f32 %0, %1\nv_cmp_lt_f32 vcc, %3, %4\n")
 KERNEL(k_readlane_like_dpp, "v_mov_b32_dpp %0, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n")
 
 typedef void (*kfn)(float *, int, float, float);
@@ -95,7 +108,11 @@ int main() {
         {"v_min_f32", k_min, 1}, {"v_min3_f32", k_min3, 1}, {"v_med3_f32", k_med3, 1}, {"v_sub_f32 |abs| e64", k_sub_abs, 1},
         {"v_add_f64", k_add_f64, 1}, {"v_mul_f64", k_mul_f64, 1}, {"v_fma_f64", k_fma_f64, 1}, {"v_cvt_f64_f32", k_cvt_f64_f32, 1}, {"v_cvt_f32_f64", k_cvt_f32_f64, 1},
         {"v_div_scale_f32", k_div_scale, 1}, {"v_div_fmas_f32", k_div_fmas, 1}, {"v_div_fixup_f32", k_div_fixup, 1},
-        {"v_add+v_mul alternating", k_mix_add_mul, 2}, {"v_mul_lo_u32", k_mul_lo_u32, 1}, {"v_mul_hi_u32", k_mul_hi_u32, 1}, {"v_mad_u64_u32", k_mad_u64_u32, 1},
+        {"v_add+v_mul alternating", k_mix_add_mul, 2}, {"v_pk_add + v_add (group of 2)", k_pk_1add, 2}, {"v_pk_mul + v_add + v_mul (group of 3)", k_pk_2add, 3},
+        {"v_cndmask + v_add (group of 2)", k_cnd_add, 2}, {"v_min3_u32 + v_add (group of 2)", k_min_add, 2}, {"v_fma_f64 + v_add_f32 (group of 2)", k_f64_add, 2},
+        {"v_add(sgpr) + v_add (group of 2)", k_sgpr_add, 2}, {"2 pk + 2 scalar (group of 4)", k_pk_pk_add_add, 4}, {"v_rsq + 3 indep v_add (group of 4)", k_rsq_indep, 4},
+        {"v_rsq + v_cmp (group of 2)", k_rsq_cmp, 2}, {"v_rsq + 3 v_add (per group of 4)", k_rsq_3add, 4}, {"v_rsq + 6 v_add (per group of 7)", k_rsq_6add, 7},
+        {"v_rsq + 2 pk (per group of 3)", k_rsq_2pk, 3}, {"v_cmp + v_add (per group of 2)", k_cmp_add, 2}, {"v_mul_lo_u32", k_mul_lo_u32, 1}, {"v_mul_hi_u32", k_mul_hi_u32, 1}, {"v_mad_u64_u32", k_mad_u64_u32, 1},
         {"v_mul_u32_u24", k_mul_u32_u24, 1}, {"v_lshrrev_b64", k_lshr_b64, 1}, {"v_xor_b32", k_xor, 1}, {"v_rsq_f64", k_rsq_f64, 1}, {"v_rcp_f64", k_rcp_f64, 1}, {"v_sqrt_f64", k_sqrt_f64, 1},
         {"v_div_scale_f64", k_div_scale_f64, 1}, {"v_div_fmas_f64", k_div_fmas_f64, 1}, {"v_div_fixup_f64", k_div_fixup_f64, 1}, {"v_ldexp_f64", k_ldexp_f64, 1},
         {"v_cvt_f64_u32", k_cvt_f64_u32, 1}, {"v_cmp_lt_f64", k_cmp_f64, 1}, {"v_pk_add_f32 (sgpr pair)", k_pk_add_sgpr, 1}, {"v_pk_add_f32 (sgpr pair, neg)", k_pk_add_sgpr_neg, 1},
