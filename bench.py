@@ -58,6 +58,28 @@ def cpu_baseline(budget_s=12.0):
                       f"(K-mode C restatement, gcc -O2 -ffp-contract=off, OpenMP)"}
 
 
+def quality_check(frame, pixels=2048):
+    """BASELINE quality metric on a strided sample of the frame just rendered: per-channel RMS between
+    the GPU's and the CPU restatement's float pixel values (after mean + clip, range [0,1]) and the
+    number of differing 8-bit PPM values.  Target <= 1e-4; the GPU path is bit-identical, so 0."""
+    import numpy as np
+    from oracle import oracle
+    fb, u8 = frame[0].cpu().numpy(), frame[1].cpu().numpy()
+    sph = oracle.gen_spheres()
+    p = oracle.make_params(W, H, S, depth=D, num_spheres=NS, mode=oracle.MODE_K, seed=0)
+    run, npix = 16, W * H
+    starts = [(k * 2654435761) % (npix - run) for k in range(pixels // run)]
+    se, diff = np.zeros(3), 0
+    for q0 in starts:
+        fb_w, u8_w, _, _ = oracle.render_frame(p, sph, pixel_begin=q0, pixel_count=run, threads=min(oracle.max_threads(), 16))
+        d = fb[:, q0:q0 + run].astype(np.float64) - fb_w.astype(np.float64)
+        se += (d * d).sum(axis=1)
+        diff += int((u8[q0:q0 + run] != u8_w).sum())
+    n = len(starts) * run
+    return {"rms_rgb": [float(x) for x in np.sqrt(se / n)], "differing_ppm_values": diff, "pixels_checked": n,
+            "reference": "oracle C restatement, K-mode", "target_rms": 1e-4}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -168,6 +190,7 @@ def main():
                          "nominal_mray_per_s": round(seg_per_rank / rms / 1e3, 1),
                          "traced_mray_per_s": round(tc.value / rms / 1e3, 1)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["quality"] = quality_check(slots[(args.steps - 1) % 2])
         out["cpu_baseline"] = cpu_baseline()
     if rank == 0:
         print(json.dumps(out), flush=True)
