@@ -14,7 +14,7 @@ APT_FLAG_RETIRE = 1
 ABI_SYMBOLS = ["apt_default_params", "render_do", "apt_set_default_params", "render_do_ex", "render_frame",
                "apt_gen_rays_device", "apt_decode_color_device", "apt_gen_rays_host", "apt_gen_spheres_host",
                "apt_gen_scene_host", "apt_write_ppm", "apt_abi_version", "apt_last_error", "apt_device_count",
-               "apt_set_trace_counter", "apt_selftest_sqrt", "apt_selftest_div3", "apt_set_refill_lanes", "apt_test_scene"]
+               "apt_set_trace_counter", "apt_selftest_sqrt", "apt_selftest_div3", "apt_set_refill_lanes", "apt_test_scene", "apt_mt19937_checkpoints_host", "apt_gen_rays_mt_device"]
 
 
 class AptError(RuntimeError):

@@ -95,6 +95,25 @@ int apt_gen_rays_host(uint32_t width, uint32_t height, uint32_t samples, uint32_
     return APT_OK;
 }
 
+// Checkpoints of the MT19937 stream for the device generator (apt_gen_rays_mt_device).  Output
+// block b (624 words = the 4 words of 156 consecutive paths) is the tempering of the state after
+// b+1 twists; checkpoint i is that raw state for block i*stride.  Sequential by nature; done once
+// per (seed, length) and reusable for every shorter length.
+int apt_mt19937_checkpoints_host(uint32_t seed, uint64_t num_blocks, uint32_t stride, uint32_t *states) {
+    if (!states || stride == 0 || num_blocks == 0) return APT_ERR_ARG;
+    uint32_t mt[624];
+    mt[0] = seed;
+    for (int i = 1; i < 624; ++i) mt[i] = 1812433253u * (mt[i - 1] ^ (mt[i - 1] >> 30)) + (uint32_t)i;
+    for (uint64_t b = 0; b < num_blocks; ++b) {
+        for (int i = 0; i < 624; ++i) { // genrand twist
+            const uint32_t y = (mt[i] & 0x80000000u) | (mt[(i + 1) % 624] & 0x7fffffffu);
+            mt[i] = mt[(i + 397) % 624] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+        }
+        if (b % stride == 0) memcpy(states + (b / stride) * 624, mt, sizeof mt);
+    }
+    return APT_OK;
+}
+
 int apt_gen_spheres_host(float *spheres128) {
     if (!spheres128) return APT_ERR_ARG;
     memset(spheres128, 0, 128 * sizeof(float));

@@ -576,6 +576,66 @@ __global__ __launch_bounds__(kBlock) void gen_rays_kernel(Camera cam, uint32_t w
     rays[3 * n_total + p] = rdx; rays[4 * n_total + p] = rdy; rays[5 * n_total + p] = rdz;
 }
 
+// ---- kernel: device gen_rays, bit-exact with the reference's MT19937 stream -------------------
+// np.random.rand() takes two MT19937 words per double and gen_rays two doubles per path, in path
+// order (gen_data.py:32-40), so output block b of the generator (624 words) is exactly paths
+// [156b, 156b+156).  One workgroup per checkpoint: load the raw state of block cb = i*stride into
+// LDS, emit that block, then `twist` forward block by block.  The twist is the textbook 3-phase
+// parallel form: x[i] depends on x[i], x[i+1] and x[i+397], so [0,227), [227,454), [454,624) can each
+// be updated at once (read, barrier, write, barrier).
+constexpr int kMtN = 624, kMtM = 397, kPathsPerBlock = 156;
+
+__device__ __forceinline__ uint32_t mt_temper(uint32_t y) {
+    y ^= y >> 11;
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= y >> 18;
+    return y;
+}
+
+__global__ __launch_bounds__(kBlock) void gen_rays_mt_kernel(const uint32_t *__restrict__ checkpoints, uint32_t stride,
+                                                             uint64_t num_blocks, Camera cam, uint32_t width,
+                                                             uint32_t height, uint32_t samples, uint64_t n_total,
+                                                             uint64_t begin, uint64_t end, float *__restrict__ rays) {
+    __shared__ uint32_t mt[kMtN];
+    const uint64_t cb = (uint64_t)blockIdx.x * stride;         // first output block of this workgroup
+    for (int i = threadIdx.x; i < kMtN; i += kBlock) mt[i] = checkpoints[(uint64_t)blockIdx.x * kMtN + i];
+    __syncthreads();
+    const uint64_t last = min(cb + stride, num_blocks);
+    for (uint64_t blk = cb; blk < last; ++blk) {
+        if (blk != cb) { // twist to the next block
+            const int t = threadIdx.x;
+            const int lo[3] = {0, 227, 454}, hi[3] = {227, 454, 624};
+#pragma unroll
+            for (int ph = 0; ph < 3; ++ph) {
+                const int i = lo[ph] + t;
+                uint32_t v = 0;
+                const bool on = i < hi[ph];
+                if (on) {
+                    const uint32_t y = (mt[i] & 0x80000000u) | (mt[(i + 1) % kMtN] & 0x7fffffffu);
+                    v = mt[(i + kMtM) % kMtN] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+                }
+                __syncthreads();
+                if (on) mt[i] = v;
+                __syncthreads();
+            }
+        }
+        const uint64_t p = blk * kPathsPerBlock + threadIdx.x;
+        if (threadIdx.x < kPathsPerBlock && p >= begin && p < end) {
+            const uint32_t a1 = mt_temper(mt[4 * threadIdx.x]) >> 5, b1 = mt_temper(mt[4 * threadIdx.x + 1]) >> 6;
+            const uint32_t a2 = mt_temper(mt[4 * threadIdx.x + 2]) >> 5, b2 = mt_temper(mt[4 * threadIdx.x + 3]) >> 6;
+            const double u1 = ((double)a1 * 67108864.0 + (double)b1) / 9007199254740992.0; // random_sample
+            const double u2 = ((double)a2 * 67108864.0 + (double)b2) / 9007199254740992.0;
+            uint32_t i, j, sy, sx;
+            path_coords(p, height, samples, i, j, sy, sx);
+            float rox, roy, roz, rdx, rdy, rdz;
+            camera_ray(cam, width, height, i, j, sy, sx, u1, u2, rox, roy, roz, rdx, rdy, rdz);
+            rays[p] = rox; rays[n_total + p] = roy; rays[2 * n_total + p] = roz;
+            rays[3 * n_total + p] = rdx; rays[4 * n_total + p] = rdy; rays[5 * n_total + p] = rdz;
+        }
+    }
+}
+
 // ---- kernel: device decode_color -----------------------------------------------------------
 __device__ float pairwise_leaf(const float *a, uint32_t n) { // numpy pairwise_sum, n <= 128
     if (n < 8) {
@@ -942,6 +1002,29 @@ int apt_gen_rays_device(const apt_render_params *p, void *stream, float *rays) {
     camera_init(cam, p->width, p->height);
     hipLaunchKernelGGL(gen_rays_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, cam, p->width,
                        p->height, p->samples, p->seed, n, b, c, rays);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? APT_OK : hip_fail(e);
+}
+
+int apt_gen_rays_mt_device(const apt_render_params *p, void *stream, const uint32_t *checkpoints, uint32_t stride,
+                           uint64_t num_checkpoints, float *rays) {
+    int rc = check_params(p);
+    if (rc) return rc;
+    if (!rays || !checkpoints || stride == 0) return fail(APT_ERR_ARG, "rays/checkpoints must be non-null, stride > 0%s");
+    const uint64_t n = (uint64_t)p->width * p->height * 4u * p->samples;
+    const uint64_t b = p->path_begin;
+    if (b > n) return fail(APT_ERR_ARG, "path_begin beyond the image%s");
+    const uint64_t c = p->path_count ? p->path_count : n - b;
+    if (b + c > n) return fail(APT_ERR_ARG, "path range beyond the image%s");
+    if (c == 0) return APT_OK;
+    const uint64_t num_blocks = (n + kPathsPerBlock - 1) / kPathsPerBlock;
+    const uint64_t need = (num_blocks + stride - 1) / stride;
+    if (num_checkpoints < need) return fail(APT_ERR_ARG, "not enough MT19937 checkpoints for this image%s");
+    if (need > 0x7fffffffull) return fail(APT_ERR_ARG, "too many checkpoints for one launch%s");
+    Camera cam;
+    camera_init(cam, p->width, p->height);
+    hipLaunchKernelGGL(gen_rays_mt_kernel, dim3((unsigned)need), dim3(kBlock), 0, (hipStream_t)stream, checkpoints,
+                       stride, num_blocks, cam, p->width, p->height, p->samples, n, b, b + c, rays);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? APT_OK : hip_fail(e);
 }

@@ -29,6 +29,36 @@ def gen_rays(w, h, s, seed=0, out_dir=None):
     return rays.reshape(6, n)
 
 
+def mt19937_checkpoints(num_paths, seed=0, stride=64):
+    """Host-made MT19937 checkpoints for gen_rays_device(): uint32 [ceil(blocks/stride)][624]."""
+    blocks = (num_paths + 155) // 156
+    n = (blocks + stride - 1) // stride
+    states = np.empty((n, 624), dtype=np.uint32)
+    check(lib().apt_mt19937_checkpoints_host(ctypes.c_uint32(seed), ctypes.c_uint64(blocks), ctypes.c_uint32(stride),
+                                             states.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32))),
+          "apt_mt19937_checkpoints_host")
+    return states
+
+
+def gen_rays_device(w, h, s, seed=0, stride=64, checkpoints=None, stream=None):
+    """gen_rays on the GPU, bit-exact with the reference (np.random.seed(seed) MT19937 stream):
+    -> torch float32 [6][N] on the device.  `checkpoints` (a CUDA int32/uint32 tensor from
+    mt19937_checkpoints) can be passed to reuse a table."""
+    import torch
+    from . import render
+    from ._lib import make_params, require_gpu
+    require_gpu()
+    p = make_params(w, h, s)
+    if checkpoints is None:
+        checkpoints = torch.from_numpy(mt19937_checkpoints(p.num_paths, seed, stride).view(np.int32)).cuda()
+    rays = torch.empty(6 * p.num_paths, dtype=torch.float32, device="cuda")
+    check(lib().apt_gen_rays_mt_device(ctypes.byref(p), render._stream_handle(stream),
+                                       ctypes.c_void_p(checkpoints.data_ptr()), ctypes.c_uint32(stride),
+                                       ctypes.c_uint64(checkpoints.shape[0]), ctypes.c_void_p(rays.data_ptr())),
+          "apt_gen_rays_mt_device")
+    return rays.view(6, -1)
+
+
 def gen_spheres(out_dir=None):
     """-> the 128-float (512-byte) [10][8] table; writes <out_dir>/spheres.bin when given."""
     sph = np.zeros(128, dtype=np.float32)

@@ -130,6 +130,18 @@ int apt_test_scene(const apt_render_params *p, void *stream, const float *rays,
  * [path_begin, path_begin+path_count) of the full buffer (same rays render_frame traces). */
 int apt_gen_rays_device(const apt_render_params *p, void *stream, float *rays);
 
+/* Device gen_rays that is BIT-EXACT with scripts/gen_data.py:21-75 under np.random.seed(seed):
+ * the MT19937 stream is regenerated on the device from host-made checkpoints (the raw 624-word
+ * state every `stride` output blocks; one block = 624 words = 156 paths).
+ *   apt_mt19937_checkpoints_host(seed, num_blocks, stride, states): states = HOST uint32
+ *       [ceil(num_blocks/stride)][624]; num_blocks = ceil(N/156).  Sequential, done once per seed;
+ *       a table made for a longer stream serves every shorter one.
+ *   apt_gen_rays_mt_device(p, stream, checkpoints_dev, stride, num_checkpoints, rays): rays [6][N],
+ *       paths [path_begin, path_begin+path_count).  p->seed is not used (the seed is in the table). */
+int apt_mt19937_checkpoints_host(uint32_t seed, uint64_t num_blocks, uint32_t stride, uint32_t *states);
+int apt_gen_rays_mt_device(const apt_render_params *p, void *stream, const uint32_t *checkpoints,
+                           uint32_t stride, uint64_t num_checkpoints, float *rays);
+
 /* Device decode_color: colors [3][N] -> fb float32 [3][W*H] (+ fb_u8 [W*H][3] or NULL),
  * same arithmetic as scripts/data_visualization.py:20-59. */
 int apt_decode_color_device(const apt_render_params *p, void *stream, const float *colors,

@@ -41,6 +41,10 @@ for mode, name in ((apt.APT_MODE_KERNEL, "K"), (apt.APT_MODE_ORACLE, "O")):
     colors = torch.empty(3 * p.num_paths, device="cuda")
     ms = timeit(lambda: render.render_do_ex(p, None, rays, sph8, colors), args.reps)
     report(f"C1 256x256 4spp D4 buffer mode {name}-mode", ms, p.num_paths * 4, 8)
+# C2 in O-mode (the NumPy oracle's arithmetic: float64-accumulated dot products in the shading step)
+p = apt.make_params(1920, 1080, 64, depth=8, mode=apt.APT_MODE_ORACLE)
+ms = timeit(lambda: render.render_frame(p, sph8), args.reps)
+report("C2 D8 1080p 256spp O-mode", ms, p.num_paths * 8, 8)
 # C2 / C5: frame mode
 for d, flags, name in ((8, 0, "C2 D8"), (8, apt.APT_FLAG_RETIRE, "C2 D8 retire"), (32, 0, "C5 D32"),
                        (32, apt.APT_FLAG_RETIRE, "C5 D32 retire")):
