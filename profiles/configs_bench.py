@@ -54,6 +54,23 @@ for d, flags, name in ((8, 0, "C2 D8"), (8, apt.APT_FLAG_RETIRE, "C2 D8 retire")
     traced = tc.value // 2
     ms = timeit(lambda: render.render_frame(p, sph8), args.reps)
     report(f"{name} 1080p 256spp", ms, p.num_paths * d, 8, {"segments_traced": traced})
+# C2 through the reference's own pipeline, entirely on the device and bit-exact with it: MT19937 gen_rays ->
+# render_do_ex on a [6][N] ray buffer (12.7 GB) -> colours [3][N] (6.4 GB) -> decode_color.  O-mode = NumPy oracle.
+import time
+t0 = time.time()
+ck = torch.from_numpy(gen_data.mt19937_checkpoints(1920 * 1080 * 4 * 64, seed=0, stride=64).view("int32")).cuda()
+t_ck = time.time() - t0
+p = apt.make_params(1920, 1080, 64, depth=8, mode=apt.APT_MODE_ORACLE)
+rays = gen_data.gen_rays_device(1920, 1080, 64, checkpoints=ck, stride=64).reshape(-1)
+colors = torch.empty(3 * p.num_paths, device="cuda")
+ms_gen = timeit(lambda: gen_data.gen_rays_device(1920, 1080, 64, checkpoints=ck, stride=64), 2)
+ms_ren = timeit(lambda: render.render_do_ex(p, None, rays, sph8, colors), 2)
+ms_dec = timeit(lambda: render.decode_color_device(p, colors), 2)
+report("C2 exact reference pipeline on device (MT19937 rays, buffer mode, O-mode)", ms_gen + ms_ren + ms_dec,
+       p.num_paths * 8, 8, {"gen_rays_ms": round(ms_gen, 2), "render_ms": round(ms_ren, 2), "decode_ms": round(ms_dec, 2),
+                            "host_checkpoint_seconds_once": round(t_ck, 2), "hbm_GB": round((9 * 4 * p.num_paths) / 1e9, 1)})
+del rays, colors, ck
+torch.cuda.empty_cache()
 # C4: 10k spheres
 scene = torch.from_numpy(gen_data.gen_scene(10000, seed=1)).cuda()
 for flags, name in ((0, ""), (apt.APT_FLAG_RETIRE, " retire")):
