@@ -420,6 +420,22 @@ APT_HD void path_uniforms(uint64_t seed, uint64_t path, double &u1, double &u2) 
     u2 = (double)(xorshift64s(s) >> 11) * (1.0 / 9007199254740992.0);
 }
 
+// ---- Russian roulette (extension, APT_FLAG_RR; specified in include/render_mi355x.h) ------------
+APT_HD uint64_t rr_path_key(uint64_t seed, uint64_t path) { return splitmix64(seed ^ splitmix64(path)); }
+APT_HD void russian_roulette(PathState &s, uint64_t key, uint32_t bounce) { // bounce: 0-based index just shaded
+    if (!s.alive) return;                       // frozen after the light: throughput no longer changes
+    float q = s.rx;
+    if (s.ry > q) q = s.ry;
+    if (s.rz > q) q = s.rz;
+    if (!(q > 0.0f)) return;                    // already (0,0,0), negative or NaN: leave it
+    float p = q < 0.05f ? 0.05f : q;
+    p = p > 0.95f ? 0.95f : p;
+    const uint64_t h = splitmix64(key + 0x9E3779B97F4A7C15ull * (uint64_t)(bounce + 1u));
+    const float u = (float)(uint32_t)(h >> 40) * 0x1p-24f;
+    if (u >= p) { s.rx = 0.0f; s.ry = 0.0f; s.rz = 0.0f; }
+    else { const float inv = 1.0f / p; s.rx = s.rx * inv; s.ry = s.ry * inv; s.rz = s.rz * inv; }
+}
+
 // path index -> (i, j, sy, sx, k):  p = (((i*H + j)*2 + sy)*2 + sx)*S + k   gen_data.py:32-36
 APT_HD void path_coords(uint64_t p, uint32_t H, uint32_t S, uint32_t &i, uint32_t &j, uint32_t &sy, uint32_t &sx) {
     uint64_t r = p / S;

@@ -58,6 +58,8 @@ struct TraceArgs {
     int32_t light;
     float eps, gain;
     uint32_t refill_lanes;      // compaction: batch size that triggers ray-generate (tuning knob)
+    uint32_t rr_start;          // Russian roulette (APT_FLAG_RR): first bounce count it applies at; 0 = off
+    uint64_t seed;              // keys the roulette draws
     unsigned long long *traced; // optional device counter of traced segments
 };
 
@@ -158,8 +160,9 @@ __device__ __forceinline__ bool bounce_ns8(const Scene8 &sc, const float4 *tab, 
 
 template <int MODE, bool RETIRE>
 __device__ __forceinline__ uint32_t trace_ns8(const Scene8 &sc, const float4 *tab, PathState &s, bool valid,
-                                              const TraceArgs &ta) {
+                                              const TraceArgs &ta, uint64_t path) {
     uint32_t traced = 0;
+    const uint64_t rr_key = ta.rr_start ? rr_path_key(ta.seed, path) : 0;
     for (uint32_t d = 0; d < ta.depth; ++d) { // render.cpp:140-188
         const bool fin = RETIRE && (!valid || path_finished(s));
         if (RETIRE && __all(fin)) break;
@@ -178,6 +181,7 @@ __device__ __forceinline__ uint32_t trace_ns8(const Scene8 &sc, const float4 *ta
                 if (ta.traced && (threadIdx.x & 63) == 0) atomicAdd(ta.traced + 3, 1ull); // statistics: exact re-runs
             }
         }
+        if (ta.rr_start && d + 1 >= ta.rr_start) russian_roulette(n, rr_key, d); // wave-uniform branch
         if (RETIRE) {
             if (!fin) { s = n; ++traced; }
         } else { // full trace: lanes past the end of the range compute garbage that is never stored
@@ -192,7 +196,8 @@ __device__ __forceinline__ uint32_t trace_ns8(const Scene8 &sc, const float4 *ta
 // Every thread of the workgroup must call this together (it contains barriers).
 template <int MODE, bool RETIRE>
 __device__ __forceinline__ uint32_t trace_dyn(const float *__restrict__ sph, float4 *tile, PathState &s, bool valid,
-                                              const TraceArgs &ta) {
+                                              const TraceArgs &ta, uint64_t path) {
+    const uint64_t rr_key = ta.rr_start ? rr_path_key(ta.seed, path) : 0;
     const uint32_t ns = ta.ns;
     const float *r2 = sph, *cx = sph + ns, *cy = sph + 2 * (size_t)ns, *cz = sph + 3 * (size_t)ns;
     const float *colx = sph + 7 * (size_t)ns, *coly = sph + 8 * (size_t)ns, *colz = sph + 9 * (size_t)ns;
@@ -247,6 +252,7 @@ __device__ __forceinline__ uint32_t trace_dyn(const float *__restrict__ sph, flo
         const uint32_t g = (idx < 0) ? ns - 1 : (uint32_t)idx;
         PathState n = s;
         shade_and_reflect<MODE>(n, tmin, cx[g], cy[g], cz[g], colx[g], coly[g], colz[g], idx == ta.light);
+        if (ta.rr_start && d + 1 >= ta.rr_start) russian_roulette(n, rr_key, d);
         if (!fin) { s = n; ++traced; }
     }
     return traced;
@@ -290,8 +296,8 @@ __global__ __launch_bounds__(kBlock) void render_paths_kernel(const float *__res
     PathState s;                                          // CopyIn: render.cpp:82-101
     path_init(s, rays[p], rays[n_total + p], rays[2 * n_total + p], rays[3 * n_total + p], rays[4 * n_total + p],
               rays[5 * n_total + p]);
-    const uint32_t traced = NS8 ? trace_ns8<MODE, RETIRE>(sc, tab, s, valid, ta)
-                                : trace_dyn<MODE, RETIRE>(sph, tile, s, valid, ta);
+    const uint32_t traced = NS8 ? trace_ns8<MODE, RETIRE>(sc, tab, s, valid, ta, p)
+                                : trace_dyn<MODE, RETIRE>(sph, tile, s, valid, ta, p);
     if (valid) {                                          // render.cpp:194-196, CopyOut :210-223
         colors[p] = s.rx * ta.gain;
         colors[n_total + p] = s.ry * ta.gain;
@@ -350,8 +356,8 @@ __global__ __launch_bounds__(kBlock, (RETIRE && NS8 && GROUP == 8) ? 5 : 1) void
         camera_ray(cam, fa.width, fa.height, pi, pj, sy, sx, u1, u2, rox, roy, roz, rdx, rdy, rdz);
         PathState s;
         path_init(s, rox, roy, roz, rdx, rdy, rdz);
-        traced += NS8 ? trace_ns8<MODE, RETIRE>(sc, tab, s, valid, ta)
-                      : trace_dyn<MODE, RETIRE>(sph, tile, s, valid, ta);
+        traced += NS8 ? trace_ns8<MODE, RETIRE>(sc, tab, s, valid, ta, pbase + k)
+                      : trace_dyn<MODE, RETIRE>(sph, tile, s, valid, ta, pbase + k);
         return Col{s.rx * ta.gain, s.ry * ta.gain, s.rz * ta.gain};
     };
     auto add = [](const Col &a, const Col &b) { return Col{a.r + b.r, a.g + b.g, a.b + b.b}; };
@@ -383,6 +389,7 @@ __global__ __launch_bounds__(kBlock, (RETIRE && NS8 && GROUP == 8) ? 5 : 1) void
                 const uint32_t qstride = 8u * lp.maxleaf;
                 uint32_t next = 0;                        // first unissued item (uniform)
                 uint32_t depth_left = 0, cur_item = 0, slot_item = 0;
+                uint64_t cur_key = 0, slot_key = 0;       // Russian-roulette keys of the running / waiting path
                 uint32_t n_bounce_exec = 0, n_gen_exec = 0; // wave-level executions (statistics only)
                 float sl_ox = 0.f, sl_oy = 0.f, sl_oz = 0.f, sl_dx = 0.f, sl_dy = 0.f, sl_dz = 1.f; // the one-ray slot
                 bool slot_full = false, slot_valid = false, cur_valid = false;
@@ -411,7 +418,9 @@ __global__ __launch_bounds__(kBlock, (RETIRE && NS8 && GROUP == 8) ? 5 : 1) void
                         if (take) {
                             slot_valid = gvalid;
                             double u1, u2;
-                            path_uniforms(fa.seed, (((uint64_t)bhi << 32) | blo) + start + k, u1, u2);
+                            const uint64_t path = (((uint64_t)bhi << 32) | blo) + start + k;
+                            if (ta.rr_start) slot_key = rr_path_key(ta.seed, path);
+                            path_uniforms(fa.seed, path, u1, u2);
                             camera_ray(cam, fa.width, fa.height, gpi, gpj, gsub >> 1, gsub & 1u, u1, u2, sl_ox, sl_oy, sl_oz, sl_dx,
                                        sl_dy, sl_dz);
                             slot_item = item;
@@ -422,6 +431,7 @@ __global__ __launch_bounds__(kBlock, (RETIRE && NS8 && GROUP == 8) ? 5 : 1) void
                     if (depth_left == 0 && slot_full) { // start the waiting ray
                         path_init(s, sl_ox, sl_oy, sl_oz, sl_dx, sl_dy, sl_dz);
                         cur_item = slot_item;
+                        cur_key = slot_key;
                         cur_valid = slot_valid;
                         depth_left = ta.depth;
                         slot_full = false;
@@ -443,6 +453,8 @@ __global__ __launch_bounds__(kBlock, (RETIRE && NS8 && GROUP == 8) ? 5 : 1) void
                         asm volatile("" ::: "memory");
                         (void)bounce_ns8<MODE, false>(sc, tab, s, nx, ta);
                     }
+                    if (ta.rr_start && ta.depth - depth_left + 1 >= ta.rr_start) // 0-based bounce index = depth - depth_left
+                        russian_roulette(nx, cur_key, ta.depth - depth_left);
                     // inactive lanes computed on stale state; whatever they hold is overwritten when
                     // they start their next ray, so the update itself needs no mask
                     s = nx;
@@ -815,6 +827,8 @@ TraceArgs make_trace_args(const apt_render_params *p) {
     ta.ns = p->num_spheres; ta.depth = p->depth; ta.light = p->light_index;
     ta.eps = p->eps; ta.gain = p->gain; ta.traced = g_trace_counter;
     ta.refill_lanes = g_refill_lanes;
+    ta.rr_start = (p->flags & APT_FLAG_RR) ? (p->rr_start ? p->rr_start : 3u) : 0u;
+    ta.seed = p->seed;
     return ta;
 }
 

@@ -52,9 +52,18 @@ enum {
 
 /* flags */
 enum {
-    APT_FLAG_RETIRE = 1u   /* result-preserving retirement of finished paths: a path     */
+    APT_FLAG_RETIRE = 1u,  /* result-preserving retirement of finished paths: a path     */
                            /* whose alive bit is cleared or whose throughput is (0,0,0)   */
                            /* stops bouncing; colours are bit-identical either way.       */
+    APT_FLAG_RR = 2u       /* EXTENSION (not in the reference; BASELINE config 5): Russian */
+                           /* roulette.  After shading bounce d (0-based) with d+1 >=       */
+                           /* rr_start, a path that is alive with q = max(r,g,b) > 0        */
+                           /* survives with probability p = clamp(q, 0.05, 0.95): u =       */
+                           /* 24-bit uniform from splitmix64(key + (d+1)*0x9E3779B97F4A7C15) */
+                           /* >> 40, key = splitmix64(seed ^ splitmix64(path index)); u >= p */
+                           /* zeroes the throughput, otherwise it is multiplied by 1/p.      */
+                           /* Unbiased; changes the image by noise only.  Same fp32 ops on   */
+                           /* GPU and in the CPU restatement (bitwise equal).                */
 };
 
 /* Run-time form of the reference's compile-time constants
@@ -71,7 +80,7 @@ typedef struct apt_render_params {
     float    gain;          /* literal 12 at render.cpp:194-196                          */
     uint32_t mode;          /* APT_MODE_*                                                */
     uint32_t flags;         /* APT_FLAG_*                                                */
-    uint32_t reserved;      /* must be 0                                                 */
+    uint32_t rr_start;      /* APT_FLAG_RR: first bounce count at which roulette applies; 0 = 3 */
     uint64_t path_begin;    /* first path index this call renders (multi-GPU shard)      */
     uint64_t path_count;    /* number of paths this call renders; 0 = all N              */
     uint64_t seed;          /* device ray generation only                                */

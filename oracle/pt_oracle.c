@@ -43,20 +43,39 @@
 #define MODE_K 0
 #define MODE_O 1
 #define FLAG_RETIRE 1u
+#define FLAG_RR 2u
 
 typedef struct {
     uint32_t struct_size, width, height, samples, depth, num_spheres;
     int32_t light_index;
     float eps, gain;
-    uint32_t mode, flags, reserved;
+    uint32_t mode, flags, rr_start;
     uint64_t path_begin, path_count, seed;
 } oracle_params; /* same layout as apt_render_params (include/render_mi355x.h) */
 
 /* ------------------------------------------------------------------------------------ */
+static uint64_t splitmix64(uint64_t x);
+/* Russian roulette (extension; spec in include/render_mi355x.h, APT_FLAG_RR) */
+static void russian_roulette(float *rx, float *ry, float *rz, int alive, uint64_t key, uint32_t bounce) {
+    if (!alive) return;
+    float q = *rx;
+    if (*ry > q) q = *ry;
+    if (*rz > q) q = *rz;
+    if (!(q > 0.0f)) return;
+    float p = q < 0.05f ? 0.05f : q;
+    p = p > 0.95f ? 0.95f : p;
+    uint64_t h = splitmix64(key + 0x9E3779B97F4A7C15ull * (uint64_t)(bounce + 1u));
+    float u = (float)(uint32_t)(h >> 40) * 0x1p-24f;
+    if (u >= p) { *rx = 0.0f; *ry = 0.0f; *rz = 0.0f; }
+    else { float inv = 1.0f / p; *rx = *rx * inv; *ry = *ry * inv; *rz = *rz * inv; }
+}
+
 /* one path, all bounces.  sph = [10][Ns] planes.                                        */
 /* returns the number of segments actually traced (== depth unless FLAG_RETIRE).         */
-static uint32_t trace_path(const oracle_params *P, const float *sph, float ox, float oy, float oz,
+static uint32_t trace_path(const oracle_params *P, const float *sph, uint64_t path, float ox, float oy, float oz,
                            float dx, float dy, float dz, float out[3]) {
+    const uint32_t rr_start = (P->flags & FLAG_RR) ? (P->rr_start ? P->rr_start : 3u) : 0u;
+    const uint64_t rr_key = rr_start ? splitmix64(P->seed ^ splitmix64(path)) : 0;
     const uint32_t Ns = P->num_spheres;
     const float *r2 = sph, *cx = sph + Ns, *cy = sph + 2 * (size_t)Ns, *cz = sph + 3 * (size_t)Ns;
     const float *colx = sph + 7 * (size_t)Ns, *coly = sph + 8 * (size_t)Ns, *colz = sph + 9 * (size_t)Ns;
@@ -126,6 +145,7 @@ static uint32_t trace_path(const oracle_params *P, const float *sph, float ox, f
         /* ---- AccumulateIntervalColor: rt_helper.h:711-830; gen_data.py:379-390 ---- */
         if (idx == (int64_t)P->light_index) alive = 0;                       /* :773-787 */
         if (alive) { retx = colx[g] * retx; rety = coly[g] * rety; retz = colz[g] * retz; } /* :799-810 */
+        if (rr_start && depth + 1 >= rr_start) russian_roulette(&retx, &rety, &retz, alive, rr_key, depth);
     }
     out[0] = retx * P->gain; out[1] = rety * P->gain; out[2] = retz * P->gain; /* render.cpp:194-196 */
     return traced;
@@ -146,7 +166,7 @@ int oracle_render_paths(const oracle_params *P, const float *rays, const float *
     for (int64_t i = 0; i < (int64_t)n; ++i) {
         const uint64_t p = b + (uint64_t)i;
         float out[3];
-        traced += trace_path(P, sph, rays[p], rays[N + p], rays[2 * N + p], rays[3 * N + p], rays[4 * N + p],
+        traced += trace_path(P, sph, p, rays[p], rays[N + p], rays[2 * N + p], rays[3 * N + p], rays[4 * N + p],
                              rays[5 * N + p], out);
         colors[p] = out[0]; colors[N + p] = out[1]; colors[2 * N + p] = out[2];
     }
@@ -424,7 +444,7 @@ int oracle_render_frame(const oracle_params *P, const float *sph, uint64_t pixel
                 double u1, u2; path_uniforms(P->seed, p, &u1, &u2);
                 float ray[6], out[3];
                 camera_ray(&cam, P->width, P->height, i, j, sy, sx, u1, u2, ray);
-                traced += trace_path(P, sph, ray[0], ray[1], ray[2], ray[3], ray[4], ray[5], out);
+                traced += trace_path(P, sph, p, ray[0], ray[1], ray[2], ray[3], ray[4], ray[5], out);
                 buf[k] = out[0]; buf[S + k] = out[1]; buf[2 * S + k] = out[2];
             }
             for (int c = 0; c < 3; ++c) m[c][sub] = pairwise_sum(buf + (size_t)c * S, S, 1) / (float)S;

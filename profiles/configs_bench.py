@@ -47,7 +47,8 @@ ms = timeit(lambda: render.render_frame(p, sph8), args.reps)
 report("C2 D8 1080p 256spp O-mode", ms, p.num_paths * 8, 8)
 # C2 / C5: frame mode
 for d, flags, name in ((8, 0, "C2 D8"), (8, apt.APT_FLAG_RETIRE, "C2 D8 retire"), (32, 0, "C5 D32"),
-                       (32, apt.APT_FLAG_RETIRE, "C5 D32 retire")):
+                       (32, apt.APT_FLAG_RETIRE, "C5 D32 retire"),
+                       (32, apt.APT_FLAG_RETIRE | apt.APT_FLAG_RR, "C5 D32 Russian roulette (rr_start 3) + retire")):
     p = apt.make_params(1920, 1080, 64, depth=d, flags=flags)
     with render.TraceCounter() as tc:
         ms = timeit(lambda: render.render_frame(p, sph8), 1)
