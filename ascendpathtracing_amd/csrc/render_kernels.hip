@@ -44,6 +44,9 @@ using namespace apt;
 constexpr int kBlock = 256;      // 4 waves
 constexpr int kTile = 1024;      // spheres per LDS tile (16 KB)
 constexpr int kMaxLeaves = 64;   // pairwise-sum leaves -> samples <= 8192
+#ifndef APT_FULL_WAVES
+#define APT_FULL_WAVES 1 // min waves per SIMD requested for the full-trace frame kernel (A/B knob)
+#endif
 constexpr int kMaxStack = 8;
 constexpr int kStackSlots = kBlock / 8; // one pairwise-sum stack per sub-pixel group (its 8 lanes hold equal values)
 constexpr uint32_t kRefillLanes = 32; // default: lanes with an empty ray slot that trigger a wave-wide ray-generate
@@ -321,7 +324,7 @@ struct FrameArgs {
 // a 3-step butterfly and no shared memory.  GROUP == 1 serves samples < 8 (numpy sums
 // those sequentially).
 template <int MODE, bool NS8, int GROUP, bool RETIRE>
-__global__ __launch_bounds__(kBlock, (RETIRE && NS8 && GROUP == 8) ? 5 : 1) void render_frame_kernel(const float *__restrict__ sph, FrameArgs fa,
+__global__ __launch_bounds__(kBlock, (RETIRE && NS8 && GROUP == 8) ? 5 : APT_FULL_WAVES) void render_frame_kernel(const float *__restrict__ sph, FrameArgs fa,
                                                               TraceArgs ta, LeafProg lp) {
     __shared__ float4 tab[16];
     __shared__ float4 tile[NS8 ? 1 : kTile];
