@@ -10,6 +10,7 @@ APT_OK = 0
 APT_MODE_KERNEL, APT_MODE_ORACLE = 0, 1
 APT_FLAG_RETIRE = 1
 APT_FLAG_RR = 2
+APT_FLAG_EMISSION = 4
 
 # every symbol include/render_mi355x.h declares
 ABI_SYMBOLS = ["apt_default_params", "render_do", "apt_set_default_params", "render_do_ex", "render_frame",

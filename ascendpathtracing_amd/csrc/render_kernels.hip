@@ -61,6 +61,7 @@ struct TraceArgs {
     int32_t light;
     float eps, gain;
     uint32_t refill_lanes;      // compaction: batch size that triggers ray-generate (tuning knob)
+    uint32_t emission;          // APT_FLAG_EMISSION: gain per channel = emission of sphere `light` instead of `gain`
     uint32_t rr_start;          // Russian roulette (APT_FLAG_RR): first bounce count it applies at; 0 = off
     uint64_t seed;              // keys the roulette draws
     unsigned long long *traced; // optional device counter of traced segments
@@ -275,6 +276,18 @@ __device__ __forceinline__ void load_scene8(const float *__restrict__ sph, Scene
     __syncthreads();
 }
 
+// render.cpp:194-196 multiplies by the literal 12; with APT_FLAG_EMISSION the light's emission planes
+// (spheres.bin rows 4..6, never read by the reference) are used instead: identical for the reference
+// scene, whose light emits (12,12,12).  Wave-uniform scalar loads.
+struct Gain3 { float r, g, b; };
+__device__ __forceinline__ Gain3 load_gain(const float *__restrict__ sph, const TraceArgs &ta) {
+    if (ta.emission) {
+        const size_t ns = ta.ns, l = (size_t)ta.light;
+        return Gain3{sph[4 * ns + l], sph[5 * ns + l], sph[6 * ns + l]};
+    }
+    return Gain3{ta.gain, ta.gain, ta.gain};
+}
+
 __device__ __forceinline__ void count_traced(const TraceArgs &ta, uint32_t traced) {
     if (ta.traced) { // one atomic per wave
         unsigned long long t = traced;
@@ -302,9 +315,10 @@ __global__ __launch_bounds__(kBlock) void render_paths_kernel(const float *__res
     const uint32_t traced = NS8 ? trace_ns8<MODE, RETIRE>(sc, tab, s, valid, ta, p)
                                 : trace_dyn<MODE, RETIRE>(sph, tile, s, valid, ta, p);
     if (valid) {                                          // render.cpp:194-196, CopyOut :210-223
-        colors[p] = s.rx * ta.gain;
-        colors[n_total + p] = s.ry * ta.gain;
-        colors[2 * n_total + p] = s.rz * ta.gain;
+        const Gain3 gain = load_gain(sph, ta);
+        colors[p] = s.rx * gain.r;
+        colors[n_total + p] = s.ry * gain.g;
+        colors[2 * n_total + p] = s.rz * gain.b;
     }
     count_traced(ta, valid ? traced : 0);
 }
@@ -351,6 +365,7 @@ __global__ __launch_bounds__(kBlock, (RETIRE && NS8 && GROUP == 8) ? 5 : APT_FUL
     const uint64_t pbase = (q * 4 + sub) * fa.samples;
     uint32_t traced = 0;
 
+    const Gain3 gain = load_gain(sph, ta);
     struct Col { float r, g, b; };
     auto sample = [&](uint32_t k) -> Col {
         double u1, u2;
@@ -361,7 +376,7 @@ __global__ __launch_bounds__(kBlock, (RETIRE && NS8 && GROUP == 8) ? 5 : APT_FUL
         path_init(s, rox, roy, roz, rdx, rdy, rdz);
         traced += NS8 ? trace_ns8<MODE, RETIRE>(sc, tab, s, valid, ta, pbase + k)
                       : trace_dyn<MODE, RETIRE>(sph, tile, s, valid, ta, pbase + k);
-        return Col{s.rx * ta.gain, s.ry * ta.gain, s.rz * ta.gain};
+        return Col{s.rx * gain.r, s.ry * gain.g, s.rz * gain.b};
     };
     auto add = [](const Col &a, const Col &b) { return Col{a.r + b.r, a.g + b.g, a.b + b.b}; };
 
@@ -440,7 +455,7 @@ __global__ __launch_bounds__(kBlock, (RETIRE && NS8 && GROUP == 8) ? 5 : APT_FUL
                         slot_full = false;
                         if (ta.depth == 0 || !cur_valid) { // depth 0, or a group past the image: colour = gain
                             depth_left = 0;
-                            colq[cur_item] = ta.gain; colq[qstride + cur_item] = ta.gain; colq[2 * qstride + cur_item] = ta.gain;
+                            colq[cur_item] = gain.r; colq[qstride + cur_item] = gain.g; colq[2 * qstride + cur_item] = gain.b;
                         }
                     }
                     const bool active = depth_left != 0;
@@ -465,9 +480,9 @@ __global__ __launch_bounds__(kBlock, (RETIRE && NS8 && GROUP == 8) ? 5 : APT_FUL
                     depth_left -= active ? 1u : 0u;
                     if (active && (depth_left == 0 || path_finished(s))) {
                         depth_left = 0;
-                        colq[cur_item] = s.rx * ta.gain;
-                        colq[qstride + cur_item] = s.ry * ta.gain;
-                        colq[2 * qstride + cur_item] = s.rz * ta.gain;
+                        colq[cur_item] = s.rx * gain.r;
+                        colq[qstride + cur_item] = s.ry * gain.g;
+                        colq[2 * qstride + cur_item] = s.rz * gain.b;
                     }
                 }
                 __syncthreads(); // colours of the whole leaf are in LDS (only wave-local data is read back)
@@ -820,6 +835,7 @@ int check_params(const apt_render_params *p) {
     if (p->mode > APT_MODE_ORACLE) return fail(APT_ERR_ARG, "unknown mode%s");
     if (p->num_spheres == 0) return fail(APT_ERR_SCENE, "num_spheres is 0%s");
     if (p->light_index >= (int32_t)p->num_spheres) return fail(APT_ERR_SCENE, "light_index out of range%s");
+    if ((p->flags & APT_FLAG_EMISSION) && p->light_index < 0) return fail(APT_ERR_SCENE, "APT_FLAG_EMISSION needs a light_index >= 0%s");
     return APT_OK;
 }
 
@@ -830,6 +846,7 @@ TraceArgs make_trace_args(const apt_render_params *p) {
     ta.ns = p->num_spheres; ta.depth = p->depth; ta.light = p->light_index;
     ta.eps = p->eps; ta.gain = p->gain; ta.traced = g_trace_counter;
     ta.refill_lanes = g_refill_lanes;
+    ta.emission = (p->flags & APT_FLAG_EMISSION) ? 1u : 0u;
     ta.rr_start = (p->flags & APT_FLAG_RR) ? (p->rr_start ? p->rr_start : 3u) : 0u;
     ta.seed = p->seed;
     return ta;

@@ -55,6 +55,9 @@ enum {
     APT_FLAG_RETIRE = 1u,  /* result-preserving retirement of finished paths: a path     */
                            /* whose alive bit is cleared or whose throughput is (0,0,0)   */
                            /* stops bouncing; colours are bit-identical either way.       */
+    APT_FLAG_EMISSION = 4u,/* colour = throughput * emission(light sphere) per channel       */
+                           /* (spheres.bin planes 4..6) instead of the literal gain 12 of      */
+                           /* render.cpp:194-196; identical on the reference scene (em = 12).  */
     APT_FLAG_RR = 2u       /* EXTENSION (not in the reference; BASELINE config 5): Russian */
                            /* roulette.  After shading bounce d (0-based) with d+1 >=       */
                            /* rr_start, a path that is alive with q = max(r,g,b) > 0        */

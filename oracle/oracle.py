@@ -16,6 +16,7 @@ _SO = os.path.join(_HERE, "libpt_oracle.so")
 MODE_K, MODE_O = 0, 1
 FLAG_RETIRE = 1
 FLAG_RR = 2
+FLAG_EMISSION = 4
 
 
 class Params(ctypes.Structure):

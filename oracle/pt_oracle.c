@@ -44,6 +44,7 @@
 #define MODE_O 1
 #define FLAG_RETIRE 1u
 #define FLAG_RR 2u
+#define FLAG_EMISSION 4u
 
 typedef struct {
     uint32_t struct_size, width, height, samples, depth, num_spheres;
@@ -147,7 +148,12 @@ static uint32_t trace_path(const oracle_params *P, const float *sph, uint64_t pa
         if (alive) { retx = colx[g] * retx; rety = coly[g] * rety; retz = colz[g] * retz; } /* :799-810 */
         if (rr_start && depth + 1 >= rr_start) russian_roulette(&retx, &rety, &retz, alive, rr_key, depth);
     }
-    out[0] = retx * P->gain; out[1] = rety * P->gain; out[2] = retz * P->gain; /* render.cpp:194-196 */
+    if ((P->flags & FLAG_EMISSION) && P->light_index >= 0) { /* emission planes 4..6 instead of the literal 12 */
+        const size_t l = (size_t)P->light_index;
+        out[0] = retx * sph[4 * (size_t)Ns + l]; out[1] = rety * sph[5 * (size_t)Ns + l]; out[2] = retz * sph[6 * (size_t)Ns + l];
+    } else {
+        out[0] = retx * P->gain; out[1] = rety * P->gain; out[2] = retz * P->gain; /* render.cpp:194-196 */
+    }
     return traced;
 }
 
