@@ -16,7 +16,7 @@ APT_FLAG_EMISSION = 4
 ABI_SYMBOLS = ["apt_default_params", "render_do", "apt_set_default_params", "render_do_ex", "render_frame",
                "apt_gen_rays_device", "apt_decode_color_device", "apt_gen_rays_host", "apt_gen_spheres_host",
                "apt_gen_scene_host", "apt_write_ppm", "apt_abi_version", "apt_last_error", "apt_device_count",
-               "apt_set_trace_counter", "apt_selftest_sqrt", "apt_selftest_div3", "apt_set_refill_lanes", "apt_test_scene", "apt_mt19937_checkpoints_host", "apt_gen_rays_mt_device"]
+               "apt_set_trace_counter", "apt_selftest_sqrt", "apt_selftest_div3", "apt_set_refill_lanes", "apt_test_scene", "apt_mt19937_checkpoints_host", "apt_gen_rays_mt_device", "apt_build_grid_host"]
 
 
 class AptError(RuntimeError):
@@ -30,7 +30,8 @@ class RenderParams(ctypes.Structure):
                 ("samples", ctypes.c_uint32), ("depth", ctypes.c_uint32), ("num_spheres", ctypes.c_uint32),
                 ("light_index", ctypes.c_int32), ("eps", ctypes.c_float), ("gain", ctypes.c_float),
                 ("mode", ctypes.c_uint32), ("flags", ctypes.c_uint32), ("rr_start", ctypes.c_uint32),
-                ("path_begin", ctypes.c_uint64), ("path_count", ctypes.c_uint64), ("seed", ctypes.c_uint64)]
+                ("path_begin", ctypes.c_uint64), ("path_count", ctypes.c_uint64), ("seed", ctypes.c_uint64),
+                ("accel", ctypes.c_uint64)]
 
     @property
     def num_paths(self):
@@ -87,13 +88,13 @@ def default_params():
 
 
 def make_params(width=16, height=16, samples=1, depth=5, num_spheres=8, light_index=None, eps=1e-4, gain=12.0,
-                mode=APT_MODE_KERNEL, flags=0, path_begin=0, path_count=0, seed=0, rr_start=0):
+                mode=APT_MODE_KERNEL, flags=0, path_begin=0, path_count=0, seed=0, rr_start=0, accel=0):
     p = default_params()
     p.width, p.height, p.samples, p.depth = width, height, samples, depth
     p.num_spheres = num_spheres
     p.light_index = num_spheres - 1 if light_index is None else light_index
     p.eps, p.gain, p.mode, p.flags, p.rr_start = eps, gain, mode, flags, rr_start
-    p.path_begin, p.path_count, p.seed = path_begin, path_count, seed
+    p.path_begin, p.path_count, p.seed, p.accel = path_begin, path_count, seed, accel
     return p
 
 

@@ -420,6 +420,19 @@ APT_HD void path_uniforms(uint64_t seed, uint64_t path, double &u1, double &u2) 
     u2 = (double)(xorshift64s(s) >> 11) * (1.0 / 9007199254740992.0);
 }
 
+// ---- uniform grid over the small spheres of a large scene ----------------------------------------
+// One flat buffer of 32-bit words, built on the host (host_helpers.cpp) and traversed on the device:
+//   GridHeader | large[nlarge] | cell_start[ncells+1] | items[nitems] | geom[Ns] as float4 (cx,cy,cz,r2)
+struct GridHeader {
+    uint32_t magic, num_spheres;
+    uint32_t n[3], ncells, nlarge, nitems;
+    uint32_t off_large, off_cells, off_items, off_geom;   // word offsets from the start of the buffer
+    float gmin[3], gmax[3], cell[3], inv_cell[3];
+    float margin;                                         // how far every small sphere's box was inflated
+    uint32_t pad[3];
+};
+constexpr uint32_t kGridMagic = 0x47524944u; // "GRID"
+
 // ---- Russian roulette (extension, APT_FLAG_RR; specified in include/render_mi355x.h) ------------
 APT_HD uint64_t rr_path_key(uint64_t seed, uint64_t path) { return splitmix64(seed ^ splitmix64(path)); }
 APT_HD void russian_roulette(PathState &s, uint64_t key, uint32_t bounce) { // bounce: 0-based index just shaded

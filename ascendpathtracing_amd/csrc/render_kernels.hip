@@ -64,6 +64,7 @@ struct TraceArgs {
     uint32_t emission;          // APT_FLAG_EMISSION: gain per channel = emission of sphere `light` instead of `gain`
     uint32_t rr_start;          // Russian roulette (APT_FLAG_RR): first bounce count it applies at; 0 = off
     uint64_t seed;              // keys the roulette draws
+    const uint32_t *grid;       // apt_render_params.accel (device) or null
     unsigned long long *traced; // optional device counter of traced segments
 };
 
@@ -262,6 +263,104 @@ __device__ __forceinline__ uint32_t trace_dyn(const float *__restrict__ sph, flo
     return traced;
 }
 
+// ---- trace: any scene through the host-built grid (apt_render_params.accel) ---------------------
+// Per lane: the always-tested large spheres, then a 3D-DDA over the cells of the small ones.  Every
+// candidate goes through the reference's exact arithmetic (intersect_pre/intersect_post), so the set
+// of (t, sphere) pairs that can win is a subset of what the brute-force loop sees, and the traversal
+// only drops spheres that cannot be hit: a sphere's box was inflated by `margin` when it was binned,
+// the walk stops only once the nearest accepted root lies clearly before the exit of the current cell,
+// and the arg-min is order independent (equal t -> lower sphere index, the brute-force loop's rule).
+// The geometric argument needs a unit-length direction (the reference's roots are only the geometric
+// ray parameters then): lanes whose |d|^2 is not within 1e-3 of 1, or not finite, test every sphere.
+template <int MODE, bool RETIRE>
+__device__ __forceinline__ uint32_t trace_grid(const float *__restrict__ sph, const uint32_t *__restrict__ grid,
+                                               PathState &s, bool valid, const TraceArgs &ta, uint64_t path) {
+    const GridHeader &h = *reinterpret_cast<const GridHeader *>(grid);
+    const uint32_t ns = ta.ns;
+    const uint32_t *large = grid + h.off_large, *cells = grid + h.off_cells, *items = grid + h.off_items;
+    const float4 *geom = reinterpret_cast<const float4 *>(grid + h.off_geom);
+    const float *colx = sph + 7 * (size_t)ns, *coly = sph + 8 * (size_t)ns, *colz = sph + 9 * (size_t)ns;
+    const uint64_t rr_key = ta.rr_start ? rr_path_key(ta.seed, path) : 0;
+    const int n0 = (int)h.n[0], n1 = (int)h.n[1], n2 = (int)h.n[2];
+    uint32_t traced = 0;
+    for (uint32_t d = 0; d < ta.depth; ++d) {
+        const bool fin = !valid || (RETIRE && path_finished(s));
+        if (RETIRE && __all(fin)) break;
+        float tmin = kMissT;
+        int idx = (MODE == kModeOracle) ? -1 : 0;
+        auto test = [&](uint32_t k) {
+            const float4 g = geom[k];
+            const HitPre hp = intersect_pre(g.x, g.y, g.z, g.w, s.ox, s.oy, s.oz, s.dx, s.dy, s.dz);
+            if (hp.disc >= 0.0f) {
+                const float t = intersect_post(hp, ta.eps);
+                if (t < tmin || (t == tmin && (int)k < idx)) { tmin = t; idx = (int)k; }
+            }
+        };
+        for (uint32_t i = 0; i < h.nlarge; ++i) test(large[i]);
+        const float dd = s.dx * s.dx + s.dy * s.dy + s.dz * s.dz;
+        const bool unit = fabsf(dd - 1.0f) <= 1e-3f; // false for NaN/inf
+        if (!fin && !unit) {
+            for (uint32_t k = 0; k < ns; ++k) test(k);
+        } else if (!fin) {
+            const float o[3] = {s.ox, s.oy, s.oz}, dv[3] = {s.dx, s.dy, s.dz};
+            float tn = 0.0f, tf = 3.0e38f;
+            bool inbox = true;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                if (fabsf(dv[a]) > 1e-20f) {
+                    const float inv = 1.0f / dv[a];
+                    const float t1 = (h.gmin[a] - o[a]) * inv, t2 = (h.gmax[a] - o[a]) * inv;
+                    tn = fmaxf(tn, fminf(t1, t2));
+                    tf = fminf(tf, fmaxf(t1, t2));
+                } else if (!(o[a] >= h.gmin[a] && o[a] <= h.gmax[a])) inbox = false;
+            }
+            if (inbox && tn <= tf) {
+                int c[3], step[3];
+                float tmax[3], tdel[3];
+#pragma unroll
+                for (int a = 0; a < 3; ++a) {
+                    const float pa = o[a] + dv[a] * tn;
+                    int ci = (int)floorf((pa - h.gmin[a]) * h.inv_cell[a]);
+                    const int na = (int)h.n[a];
+                    ci = ci < 0 ? 0 : (ci >= na ? na - 1 : ci);
+                    c[a] = ci;
+                    if (dv[a] > 1e-20f) {
+                        step[a] = 1;
+                        tmax[a] = (h.gmin[a] + (float)(ci + 1) * h.cell[a] - o[a]) / dv[a];
+                        tdel[a] = h.cell[a] / dv[a];
+                    } else if (dv[a] < -1e-20f) {
+                        step[a] = -1;
+                        tmax[a] = (h.gmin[a] + (float)ci * h.cell[a] - o[a]) / dv[a];
+                        tdel[a] = -h.cell[a] / dv[a];
+                    } else {
+                        step[a] = 0;
+                        tmax[a] = 3.0e38f;
+                        tdel[a] = 3.0e38f;
+                    }
+                }
+                const int max_steps = n0 + n1 + n2 + 3;
+                for (int it = 0; it < max_steps; ++it) {
+                    const uint32_t cell = (uint32_t)((c[2] * n1 + c[1]) * n0 + c[0]);
+                    const uint32_t b = cells[cell], e = cells[cell + 1];
+                    for (uint32_t i = b; i < e; ++i) test(items[i]);
+                    const float te = fminf(tmax[0], fminf(tmax[1], tmax[2]));            // parameter at which the ray leaves this cell
+                    if (tmin < te - (1e-3f * fabsf(te) + h.margin)) break;             // nothing nearer can lie ahead
+                    if (tmax[0] <= tmax[1] && tmax[0] <= tmax[2]) { c[0] += step[0]; tmax[0] += tdel[0]; if ((unsigned)c[0] >= (unsigned)n0) break; }
+                    else if (tmax[1] <= tmax[2]) { c[1] += step[1]; tmax[1] += tdel[1]; if ((unsigned)c[1] >= (unsigned)n1) break; }
+                    else { c[2] += step[2]; tmax[2] += tdel[2]; if ((unsigned)c[2] >= (unsigned)n2) break; }
+                }
+            }
+        }
+        const uint32_t g = (idx < 0) ? ns - 1 : (uint32_t)idx;
+        const float4 gc = geom[g];
+        PathState n = s;
+        shade_and_reflect<MODE>(n, tmin, gc.x, gc.y, gc.z, colx[g], coly[g], colz[g], idx == ta.light);
+        if (ta.rr_start && d + 1 >= ta.rr_start) russian_roulette(n, rr_key, d);
+        if (!fin) { s = n; ++traced; }
+    }
+    return traced;
+}
+
 // spheres.bin layout [10][8]: r2, x, y, z, em*3, col*3 (gen_data.py:106-127, rt_helper.h:93-102)
 __device__ __forceinline__ void load_scene8(const float *__restrict__ sph, Scene8 &sc, float4 *tab) {
 #pragma unroll
@@ -313,7 +412,8 @@ __global__ __launch_bounds__(kBlock) void render_paths_kernel(const float *__res
     path_init(s, rays[p], rays[n_total + p], rays[2 * n_total + p], rays[3 * n_total + p], rays[4 * n_total + p],
               rays[5 * n_total + p]);
     const uint32_t traced = NS8 ? trace_ns8<MODE, RETIRE>(sc, tab, s, valid, ta, p)
-                                : trace_dyn<MODE, RETIRE>(sph, tile, s, valid, ta, p);
+                                : (ta.grid ? trace_grid<MODE, RETIRE>(sph, ta.grid, s, valid, ta, p)
+                                           : trace_dyn<MODE, RETIRE>(sph, tile, s, valid, ta, p));
     if (valid) {                                          // render.cpp:194-196, CopyOut :210-223
         const Gain3 gain = load_gain(sph, ta);
         colors[p] = s.rx * gain.r;
@@ -375,7 +475,8 @@ __global__ __launch_bounds__(kBlock, (RETIRE && NS8 && GROUP == 8) ? 5 : APT_FUL
         PathState s;
         path_init(s, rox, roy, roz, rdx, rdy, rdz);
         traced += NS8 ? trace_ns8<MODE, RETIRE>(sc, tab, s, valid, ta, pbase + k)
-                      : trace_dyn<MODE, RETIRE>(sph, tile, s, valid, ta, pbase + k);
+                      : (ta.grid ? trace_grid<MODE, RETIRE>(sph, ta.grid, s, valid, ta, pbase + k)
+                                 : trace_dyn<MODE, RETIRE>(sph, tile, s, valid, ta, pbase + k));
         return Col{s.rx * gain.r, s.ry * gain.g, s.rz * gain.b};
     };
     auto add = [](const Col &a, const Col &b) { return Col{a.r + b.r, a.g + b.g, a.b + b.b}; };
@@ -846,6 +947,7 @@ TraceArgs make_trace_args(const apt_render_params *p) {
     ta.ns = p->num_spheres; ta.depth = p->depth; ta.light = p->light_index;
     ta.eps = p->eps; ta.gain = p->gain; ta.traced = g_trace_counter;
     ta.refill_lanes = g_refill_lanes;
+    ta.grid = (p->num_spheres != 8) ? reinterpret_cast<const uint32_t *>((uintptr_t)p->accel) : nullptr;
     ta.emission = (p->flags & APT_FLAG_EMISSION) ? 1u : 0u;
     ta.rr_start = (p->flags & APT_FLAG_RR) ? (p->rr_start ? p->rr_start : 3u) : 0u;
     ta.seed = p->seed;

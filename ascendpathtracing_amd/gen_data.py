@@ -82,6 +82,19 @@ def gen_scene(num_spheres, seed=0, out_dir=None):
     return sph
 
 
+def build_grid(spheres, num_spheres):
+    """Host-built uniform grid for a large scene (apt_build_grid_host) -> uint32 numpy buffer to copy to the
+    device; pass its device address as RenderParams.accel."""
+    spheres = np.ascontiguousarray(spheres, dtype=np.float32).ravel()
+    nbytes = ctypes.c_size_t(0)
+    check(lib().apt_build_grid_host(_fptr(spheres), ctypes.c_uint32(num_spheres), None, ctypes.byref(nbytes)),
+          "apt_build_grid_host")
+    buf = np.zeros(nbytes.value // 4, dtype=np.uint32)
+    check(lib().apt_build_grid_host(_fptr(spheres), ctypes.c_uint32(num_spheres),
+                                    buf.ctypes.data_as(ctypes.c_void_p), ctypes.byref(nbytes)), "apt_build_grid_host")
+    return buf
+
+
 if __name__ == "__main__":              # gen_data.py:435-446
     os.makedirs("input", exist_ok=True)
     gen_rays(width, height, samples, seed=0, out_dir="./input")

@@ -87,6 +87,7 @@ typedef struct apt_render_params {
     uint64_t path_begin;    /* first path index this call renders (multi-GPU shard)      */
     uint64_t path_count;    /* number of paths this call renders; 0 = all N              */
     uint64_t seed;          /* device ray generation only                                */
+    uint64_t accel;         /* DEVICE address of a grid built by apt_build_grid_host, or 0 */
 } apt_render_params;
 
 /* Fill *p with the reference defaults: 16x16, samples 1, depth 5, 8 spheres, light 7,
@@ -174,6 +175,15 @@ int apt_gen_spheres_host(float *spheres128);
  * padded length.  Pass spheres == NULL to query the length. */
 int apt_gen_scene_host(uint32_t num_spheres, uint64_t seed, float *spheres,
                        size_t *out_floats);
+
+/* Acceleration structure for scenes far larger than LDS (num_spheres != 8): a uniform grid over the
+ * small spheres plus an always-tested list of the large ones (walls, light).  Built on the HOST from
+ * the same [10][Ns] table the kernels read; the caller copies the `*out_bytes` bytes to the device and
+ * passes that address in apt_render_params.accel.  Pass grid == NULL to query the size.  Rendering
+ * with it is bit-identical to rendering without: every candidate goes through the reference's exact
+ * intersection arithmetic, the traversal only skips spheres that provably cannot be hit, and ties keep
+ * the lowest sphere index. */
+int apt_build_grid_host(const float *spheres_host, uint32_t num_spheres, void *grid, size_t *out_bytes);
 
 /* P3 writer of scripts/data_visualization.py:11-17 from a [pixel][3] uint8 image in
  * x-major pixel order (q = i*H + j, y not flipped). */

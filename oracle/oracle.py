@@ -25,18 +25,19 @@ class Params(ctypes.Structure):
                 ("samples", ctypes.c_uint32), ("depth", ctypes.c_uint32), ("num_spheres", ctypes.c_uint32),
                 ("light_index", ctypes.c_int32), ("eps", ctypes.c_float), ("gain", ctypes.c_float),
                 ("mode", ctypes.c_uint32), ("flags", ctypes.c_uint32), ("rr_start", ctypes.c_uint32),
-                ("path_begin", ctypes.c_uint64), ("path_count", ctypes.c_uint64), ("seed", ctypes.c_uint64)]
+                ("path_begin", ctypes.c_uint64), ("path_count", ctypes.c_uint64), ("seed", ctypes.c_uint64),
+                ("accel", ctypes.c_uint64)]
 
 
 def make_params(width=16, height=16, samples=1, depth=5, num_spheres=8, light_index=None, eps=1e-4, gain=12.0,
-                mode=MODE_K, flags=0, path_begin=0, path_count=0, seed=0, rr_start=0):
+                mode=MODE_K, flags=0, path_begin=0, path_count=0, seed=0, rr_start=0, accel=0):
     p = Params()
     p.struct_size = ctypes.sizeof(Params)
     p.width, p.height, p.samples, p.depth = width, height, samples, depth
     p.num_spheres = num_spheres
     p.light_index = num_spheres - 1 if light_index is None else light_index
     p.eps, p.gain, p.mode, p.flags, p.rr_start = eps, gain, mode, flags, rr_start
-    p.path_begin, p.path_count, p.seed = path_begin, path_count, seed
+    p.path_begin, p.path_count, p.seed, p.accel = path_begin, path_count, seed, accel
     return p
 
 

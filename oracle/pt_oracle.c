@@ -51,7 +51,7 @@ typedef struct {
     int32_t light_index;
     float eps, gain;
     uint32_t mode, flags, rr_start;
-    uint64_t path_begin, path_count, seed;
+    uint64_t path_begin, path_count, seed, accel; /* accel: ignored here (brute force is the reference) */
 } oracle_params; /* same layout as apt_render_params (include/render_mi355x.h) */
 
 /* ------------------------------------------------------------------------------------ */

@@ -37,7 +37,7 @@ def test_every_declared_symbol_is_exported(apt):
 
 def test_params_struct_layout_matches_header(apt):
     p = apt.default_params()
-    assert ctypes.sizeof(apt.RenderParams) == 72 == p.struct_size
+    assert ctypes.sizeof(apt.RenderParams) == 80 == p.struct_size
     # the reference's compile-time constants: common.h:4-10, render.cpp:141,194
     assert (p.width, p.height, p.samples, p.depth, p.num_spheres, p.light_index) == (16, 16, 1, 5, 8, 7)
     assert np.float32(p.eps) == np.float32(1e-4) and p.gain == 12.0 and p.mode == apt.APT_MODE_KERNEL and p.flags == 0
@@ -102,3 +102,27 @@ def test_compute_entries_fail_loudly_without_a_gpu(apt):
     with pytest.raises(apt.AptError, match="no HIP device"):
         render.render_do(8, None, 0, torch.zeros(6), torch.zeros(128), torch.zeros(3))
     assert apt._lib.lib().apt_device_count() == 0
+
+
+def test_grid_builder_layout(apt):
+    """apt_build_grid_host: header, always-tested list (walls + light), every small sphere listed in every
+    cell its inflated box touches, ascending sphere order inside a cell."""
+    ns = 500
+    scene = apt.gen_data.gen_scene(ns, seed=4)
+    g = apt.gen_data.build_grid(scene, ns)
+    hdr = g[:12]
+    assert hdr[0] == 0x47524944 and hdr[1] == ns
+    n, ncells, nlarge, nitems = hdr[2:5], hdr[5], hdr[6], hdr[7]
+    off_large, off_cells, off_items, off_geom = hdr[8:12]
+    assert int(np.prod(n)) == ncells and nlarge == 7
+    assert sorted(g[off_large:off_large + nlarge].tolist()) == [0, 1, 2, 3, 4, 5, ns - 1]
+    starts = g[off_cells:off_cells + ncells + 1]
+    assert starts[0] == 0 and starts[-1] == nitems and (np.diff(starts.astype(np.int64)) >= 0).all()
+    items = g[off_items:off_items + nitems]
+    for c in range(0, ncells, max(1, ncells // 50)):
+        lst = items[starts[c]:starts[c + 1]]
+        assert (np.diff(lst.astype(np.int64)) > 0).all()
+    assert set(items.tolist()) == set(range(6, ns - 1))
+    geom = g[off_geom:off_geom + 4 * ns].view(np.float32).reshape(ns, 4)
+    tab = scene[:10 * ns].reshape(10, ns)
+    assert np.array_equal(geom[:, 0], tab[1]) and np.array_equal(geom[:, 3], tab[0])
