@@ -221,7 +221,8 @@ int apt_build_grid_host(const float *sph, uint32_t ns, void *grid, size_t *out_b
     h.off_cells = h.off_large + h.nlarge;
     h.off_items = h.off_cells + h.ncells + 1;
     h.off_geom = (h.off_items + h.nitems + 3u) & ~3u;                               // 16-byte aligned float4s
-    const size_t words = (size_t)h.off_geom + 4 * (size_t)ns;
+    h.off_item_geom = h.off_geom + 4 * ns;
+    const size_t words = (size_t)h.off_item_geom + 4 * (size_t)h.nitems;
     *out_bytes = words * 4;
     if (!grid) return APT_OK;
     uint32_t *w = (uint32_t *)grid;
@@ -238,6 +239,8 @@ int apt_build_grid_host(const float *sph, uint32_t ns, void *grid, size_t *out_b
     }
     float *g = (float *)(w + h.off_geom);
     for (uint32_t k = 0; k < ns; ++k) { g[4 * k] = cx[k]; g[4 * k + 1] = cy[k]; g[4 * k + 2] = cz[k]; g[4 * k + 3] = r2[k]; }
+    float *ig = (float *)(w + h.off_item_geom);
+    for (uint32_t i = 0; i < h.nitems; ++i) memcpy(ig + 4 * (size_t)i, g + 4 * (size_t)w[h.off_items + i], 16);
     return APT_OK;
 }
 

@@ -422,14 +422,17 @@ APT_HD void path_uniforms(uint64_t seed, uint64_t path, double &u1, double &u2) 
 
 // ---- uniform grid over the small spheres of a large scene ----------------------------------------
 // One flat buffer of 32-bit words, built on the host (host_helpers.cpp) and traversed on the device:
-//   GridHeader | large[nlarge] | cell_start[ncells+1] | items[nitems] | geom[Ns] as float4 (cx,cy,cz,r2)
+//   GridHeader | large[nlarge] | cell_start[ncells+1] | items[nitems] | geom[Ns] float4 (cx,cy,cz,r2)
+//              | item_geom[nitems] float4 = geom[items[i]]  (cell order: the walk reads it directly, one
+//                dependent load fewer per candidate)
 struct GridHeader {
     uint32_t magic, num_spheres;
     uint32_t n[3], ncells, nlarge, nitems;
     uint32_t off_large, off_cells, off_items, off_geom;   // word offsets from the start of the buffer
+    uint32_t off_item_geom;
     float gmin[3], gmax[3], cell[3], inv_cell[3];
     float margin;                                         // how far every small sphere's box was inflated
-    uint32_t pad[3];
+    uint32_t pad[2];
 };
 constexpr uint32_t kGridMagic = 0x47524944u; // "GRID"
 

@@ -42,6 +42,7 @@ namespace {
 using namespace apt;
 
 constexpr int kBlock = 256;      // 4 waves
+constexpr int kScene8 = 0, kSceneTiles = 1, kSceneGrid = 2; // template parameter SC: how the scene reaches the lanes
 constexpr int kTile = 1024;      // spheres per LDS tile (16 KB)
 constexpr int kMaxLeaves = 64;   // pairwise-sum leaves -> samples <= 8192
 #ifndef APT_FULL_WAVES
@@ -279,75 +280,77 @@ __device__ __forceinline__ uint32_t trace_grid(const float *__restrict__ sph, co
     const uint32_t ns = ta.ns;
     const uint32_t *large = grid + h.off_large, *cells = grid + h.off_cells, *items = grid + h.off_items;
     const float4 *geom = reinterpret_cast<const float4 *>(grid + h.off_geom);
+    const float4 *item_geom = reinterpret_cast<const float4 *>(grid + h.off_item_geom);
     const float *colx = sph + 7 * (size_t)ns, *coly = sph + 8 * (size_t)ns, *colz = sph + 9 * (size_t)ns;
     const uint64_t rr_key = ta.rr_start ? rr_path_key(ta.seed, path) : 0;
     const int n0 = (int)h.n[0], n1 = (int)h.n[1], n2 = (int)h.n[2];
-    uint32_t traced = 0;
+    uint32_t traced = 0, n_cells = 0, n_tests = 0; // statistics
     for (uint32_t d = 0; d < ta.depth; ++d) {
         const bool fin = !valid || (RETIRE && path_finished(s));
         if (RETIRE && __all(fin)) break;
         float tmin = kMissT;
         int idx = (MODE == kModeOracle) ? -1 : 0;
-        auto test = [&](uint32_t k) {
-            const float4 g = geom[k];
+        auto test_geom = [&](const float4 g, uint32_t k) {
+            ++n_tests;
             const HitPre hp = intersect_pre(g.x, g.y, g.z, g.w, s.ox, s.oy, s.oz, s.dx, s.dy, s.dz);
             if (hp.disc >= 0.0f) {
                 const float t = intersect_post(hp, ta.eps);
                 if (t < tmin || (t == tmin && (int)k < idx)) { tmin = t; idx = (int)k; }
             }
         };
-        for (uint32_t i = 0; i < h.nlarge; ++i) test(large[i]);
+        auto test = [&](uint32_t k) { test_geom(geom[k], k); };
+        for (uint32_t i = 0; i < h.nlarge; ++i) test(large[i]); // wave-uniform: scalar loads
         const float dd = s.dx * s.dx + s.dy * s.dy + s.dz * s.dz;
         const bool unit = fabsf(dd - 1.0f) <= 1e-3f; // false for NaN/inf
         if (!fin && !unit) {
             for (uint32_t k = 0; k < ns; ++k) test(k);
         } else if (!fin) {
-            const float o[3] = {s.ox, s.oy, s.oz}, dv[3] = {s.dx, s.dy, s.dz};
+            // slab test against the grid box; all DDA state in scalars (no indexed arrays -> no scratch)
             float tn = 0.0f, tf = 3.0e38f;
             bool inbox = true;
-#pragma unroll
-            for (int a = 0; a < 3; ++a) {
-                if (fabsf(dv[a]) > 1e-20f) {
-                    const float inv = 1.0f / dv[a];
-                    const float t1 = (h.gmin[a] - o[a]) * inv, t2 = (h.gmax[a] - o[a]) * inv;
+            auto slab = [&](float o, float dv, float lo, float hi) {
+                if (fabsf(dv) > 1e-20f) {
+                    const float inv = 1.0f / dv, t1 = (lo - o) * inv, t2 = (hi - o) * inv;
                     tn = fmaxf(tn, fminf(t1, t2));
                     tf = fminf(tf, fmaxf(t1, t2));
-                } else if (!(o[a] >= h.gmin[a] && o[a] <= h.gmax[a])) inbox = false;
-            }
+                } else if (!(o >= lo && o <= hi)) inbox = false;
+            };
+            slab(s.ox, s.dx, h.gmin[0], h.gmax[0]);
+            slab(s.oy, s.dy, h.gmin[1], h.gmax[1]);
+            slab(s.oz, s.dz, h.gmin[2], h.gmax[2]);
             if (inbox && tn <= tf) {
-                int c[3], step[3];
-                float tmax[3], tdel[3];
-#pragma unroll
-                for (int a = 0; a < 3; ++a) {
-                    const float pa = o[a] + dv[a] * tn;
-                    int ci = (int)floorf((pa - h.gmin[a]) * h.inv_cell[a]);
-                    const int na = (int)h.n[a];
+                auto axis = [&](float o, float dv, float lo, float cellw, float invw, int na, int &c, int &step, float &tmax,
+                                float &tdel) {
+                    int ci = (int)floorf((o + dv * tn - lo) * invw);
                     ci = ci < 0 ? 0 : (ci >= na ? na - 1 : ci);
-                    c[a] = ci;
-                    if (dv[a] > 1e-20f) {
-                        step[a] = 1;
-                        tmax[a] = (h.gmin[a] + (float)(ci + 1) * h.cell[a] - o[a]) / dv[a];
-                        tdel[a] = h.cell[a] / dv[a];
-                    } else if (dv[a] < -1e-20f) {
-                        step[a] = -1;
-                        tmax[a] = (h.gmin[a] + (float)ci * h.cell[a] - o[a]) / dv[a];
-                        tdel[a] = -h.cell[a] / dv[a];
-                    } else {
-                        step[a] = 0;
-                        tmax[a] = 3.0e38f;
-                        tdel[a] = 3.0e38f;
-                    }
-                }
+                    c = ci;
+                    if (dv > 1e-20f) { step = 1; tmax = (lo + (float)(ci + 1) * cellw - o) / dv; tdel = cellw / dv; }
+                    else if (dv < -1e-20f) { step = -1; tmax = (lo + (float)ci * cellw - o) / dv; tdel = -cellw / dv; }
+                    else { step = 0; tmax = 3.0e38f; tdel = 3.0e38f; }
+                };
+                int c0, c1, c2, st0, st1, st2;
+                float tm0, tm1, tm2, td0, td1, td2;
+                axis(s.ox, s.dx, h.gmin[0], h.cell[0], h.inv_cell[0], n0, c0, st0, tm0, td0);
+                axis(s.oy, s.dy, h.gmin[1], h.cell[1], h.inv_cell[1], n1, c1, st1, tm1, td1);
+                axis(s.oz, s.dz, h.gmin[2], h.cell[2], h.inv_cell[2], n2, c2, st2, tm2, td2);
                 const int max_steps = n0 + n1 + n2 + 3;
                 for (int it = 0; it < max_steps; ++it) {
-                    const uint32_t cell = (uint32_t)((c[2] * n1 + c[1]) * n0 + c[0]);
+                    const uint32_t cell = (uint32_t)((c2 * n1 + c1) * n0 + c0);
                     const uint32_t b = cells[cell], e = cells[cell + 1];
-                    for (uint32_t i = b; i < e; ++i) test(items[i]);
-                    const float te = fminf(tmax[0], fminf(tmax[1], tmax[2]));            // parameter at which the ray leaves this cell
+                    ++n_cells;
+                    uint32_t i = b;
+                    for (; i + 2 <= e; i += 2) { // two candidates per step: four independent loads in flight
+                        const float4 ga = item_geom[i], gb = item_geom[i + 1];
+                        const uint32_t ka = items[i], kb = items[i + 1];
+                        test_geom(ga, ka);
+                        test_geom(gb, kb);
+                    }
+                    if (i < e) test_geom(item_geom[i], items[i]);
+                    const float te = fminf(tm0, fminf(tm1, tm2));                      // parameter at which the ray leaves this cell
                     if (tmin < te - (1e-3f * fabsf(te) + h.margin)) break;             // nothing nearer can lie ahead
-                    if (tmax[0] <= tmax[1] && tmax[0] <= tmax[2]) { c[0] += step[0]; tmax[0] += tdel[0]; if ((unsigned)c[0] >= (unsigned)n0) break; }
-                    else if (tmax[1] <= tmax[2]) { c[1] += step[1]; tmax[1] += tdel[1]; if ((unsigned)c[1] >= (unsigned)n1) break; }
-                    else { c[2] += step[2]; tmax[2] += tdel[2]; if ((unsigned)c[2] >= (unsigned)n2) break; }
+                    if (tm0 <= tm1 && tm0 <= tm2) { c0 += st0; tm0 += td0; if ((unsigned)c0 >= (unsigned)n0) break; }
+                    else if (tm1 <= tm2) { c1 += st1; tm1 += td1; if ((unsigned)c1 >= (unsigned)n1) break; }
+                    else { c2 += st2; tm2 += td2; if ((unsigned)c2 >= (unsigned)n2) break; }
                 }
             }
         }
@@ -357,6 +360,11 @@ __device__ __forceinline__ uint32_t trace_grid(const float *__restrict__ sph, co
         shade_and_reflect<MODE>(n, tmin, gc.x, gc.y, gc.z, colx[g], coly[g], colz[g], idx == ta.light);
         if (ta.rr_start && d + 1 >= ta.rr_start) russian_roulette(n, rr_key, d);
         if (!fin) { s = n; ++traced; }
+    }
+    if (ta.traced) { // statistics: cells visited / candidates tested (per lane, summed over the wave)
+        unsigned long long c = n_cells, t = n_tests;
+        for (int off = 32; off > 0; off >>= 1) { c += __shfl_xor(c, off, 64); t += __shfl_xor(t, off, 64); }
+        if ((threadIdx.x & 63) == 0) { atomicAdd(ta.traced + 1, c); atomicAdd(ta.traced + 2, t); }
     }
     return traced;
 }
@@ -396,13 +404,14 @@ __device__ __forceinline__ void count_traced(const TraceArgs &ta, uint32_t trace
 }
 
 // ---- kernel: rays from a buffer ---------------------------------------------------------
-template <int MODE, bool NS8, bool RETIRE>
+template <int MODE, int SC, bool RETIRE>
 __global__ __launch_bounds__(kBlock) void render_paths_kernel(const float *__restrict__ rays,
                                                               const float *__restrict__ sph,
                                                               float *__restrict__ colors, uint64_t n_total,
                                                               uint64_t begin, uint64_t count, TraceArgs ta) {
+    constexpr bool NS8 = SC == kScene8;
     __shared__ float4 tab[16];
-    __shared__ float4 tile[NS8 ? 1 : kTile];
+    __shared__ float4 tile[SC == kSceneTiles ? kTile : 1];
     Scene8 sc;
     if (NS8) load_scene8(sph, sc, tab);
     const uint64_t local = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -411,9 +420,10 @@ __global__ __launch_bounds__(kBlock) void render_paths_kernel(const float *__res
     PathState s;                                          // CopyIn: render.cpp:82-101
     path_init(s, rays[p], rays[n_total + p], rays[2 * n_total + p], rays[3 * n_total + p], rays[4 * n_total + p],
               rays[5 * n_total + p]);
-    const uint32_t traced = NS8 ? trace_ns8<MODE, RETIRE>(sc, tab, s, valid, ta, p)
-                                : (ta.grid ? trace_grid<MODE, RETIRE>(sph, ta.grid, s, valid, ta, p)
-                                           : trace_dyn<MODE, RETIRE>(sph, tile, s, valid, ta, p));
+    uint32_t traced;
+    if (SC == kScene8) traced = trace_ns8<MODE, RETIRE>(sc, tab, s, valid, ta, p);
+    else if (SC == kSceneGrid) traced = trace_grid<MODE, RETIRE>(sph, ta.grid, s, valid, ta, p);
+    else traced = trace_dyn<MODE, RETIRE>(sph, tile, s, valid, ta, p);
     if (valid) {                                          // render.cpp:194-196, CopyOut :210-223
         const Gain3 gain = load_gain(sph, ta);
         colors[p] = s.rx * gain.r;
@@ -437,11 +447,12 @@ struct FrameArgs {
 // r[j] (samples j, 8+j, 16+j, ...), so the summation order of np.mean is reproduced with
 // a 3-step butterfly and no shared memory.  GROUP == 1 serves samples < 8 (numpy sums
 // those sequentially).
-template <int MODE, bool NS8, int GROUP, bool RETIRE>
-__global__ __launch_bounds__(kBlock, (RETIRE && NS8 && GROUP == 8) ? 5 : APT_FULL_WAVES) void render_frame_kernel(const float *__restrict__ sph, FrameArgs fa,
+template <int MODE, int SC, int GROUP, bool RETIRE>
+__global__ __launch_bounds__(kBlock, (RETIRE && SC == kScene8 && GROUP == 8) ? 5 : APT_FULL_WAVES) void render_frame_kernel(const float *__restrict__ sph, FrameArgs fa,
                                                               TraceArgs ta, LeafProg lp) {
+    constexpr bool NS8 = SC == kScene8;
     __shared__ float4 tab[16];
-    __shared__ float4 tile[NS8 ? 1 : kTile];
+    __shared__ float4 tile[SC == kSceneTiles ? kTile : 1];
     extern __shared__ float dyn_lds[];
     float *stack_lds = dyn_lds;                                            // [kMaxStack][3][kStackSlots] when lp.nleaves > 1
     float *queue_lds = dyn_lds + (lp.nleaves > 1 ? kMaxStack * 3 * kStackSlots : 0); // [waves][3][8*maxleaf] (refill)
@@ -474,9 +485,9 @@ __global__ __launch_bounds__(kBlock, (RETIRE && NS8 && GROUP == 8) ? 5 : APT_FUL
         camera_ray(cam, fa.width, fa.height, pi, pj, sy, sx, u1, u2, rox, roy, roz, rdx, rdy, rdz);
         PathState s;
         path_init(s, rox, roy, roz, rdx, rdy, rdz);
-        traced += NS8 ? trace_ns8<MODE, RETIRE>(sc, tab, s, valid, ta, pbase + k)
-                      : (ta.grid ? trace_grid<MODE, RETIRE>(sph, ta.grid, s, valid, ta, pbase + k)
-                                 : trace_dyn<MODE, RETIRE>(sph, tile, s, valid, ta, pbase + k));
+        if (SC == kScene8) traced += trace_ns8<MODE, RETIRE>(sc, tab, s, valid, ta, pbase + k);
+        else if (SC == kSceneGrid) traced += trace_grid<MODE, RETIRE>(sph, ta.grid, s, valid, ta, pbase + k);
+        else traced += trace_dyn<MODE, RETIRE>(sph, tile, s, valid, ta, pbase + k);
         return Col{s.rx * gain.r, s.ry * gain.g, s.rz * gain.b};
     };
     auto add = [](const Col &a, const Col &b) { return Col{a.r + b.r, a.g + b.g, a.b + b.b}; };
@@ -954,25 +965,25 @@ TraceArgs make_trace_args(const apt_render_params *p) {
     return ta;
 }
 
-template <int MODE, bool NS8>
+template <int MODE, int SC>
 void launch_paths(bool retire, dim3 grid, hipStream_t st, const float *rays, const float *sph, float *colors,
                   uint64_t n, uint64_t b, uint64_t c, const TraceArgs &ta) {
-    if (retire) hipLaunchKernelGGL((render_paths_kernel<MODE, NS8, true>), grid, dim3(kBlock), 0, st, rays, sph, colors, n, b, c, ta);
-    else hipLaunchKernelGGL((render_paths_kernel<MODE, NS8, false>), grid, dim3(kBlock), 0, st, rays, sph, colors, n, b, c, ta);
+    if (retire) hipLaunchKernelGGL((render_paths_kernel<MODE, SC, true>), grid, dim3(kBlock), 0, st, rays, sph, colors, n, b, c, ta);
+    else hipLaunchKernelGGL((render_paths_kernel<MODE, SC, false>), grid, dim3(kBlock), 0, st, rays, sph, colors, n, b, c, ta);
 }
 
-template <int MODE, bool NS8, int GROUP>
+template <int MODE, int SC, int GROUP>
 void launch_frame(bool retire, dim3 grid, size_t lds, hipStream_t st, const float *sph, const FrameArgs &fa,
                   const TraceArgs &ta, const LeafProg &lp) {
-    if (retire) hipLaunchKernelGGL((render_frame_kernel<MODE, NS8, GROUP, true>), grid, dim3(kBlock), lds, st, sph, fa, ta, lp);
-    else hipLaunchKernelGGL((render_frame_kernel<MODE, NS8, GROUP, false>), grid, dim3(kBlock), lds, st, sph, fa, ta, lp);
+    if (retire) hipLaunchKernelGGL((render_frame_kernel<MODE, SC, GROUP, true>), grid, dim3(kBlock), lds, st, sph, fa, ta, lp);
+    else hipLaunchKernelGGL((render_frame_kernel<MODE, SC, GROUP, false>), grid, dim3(kBlock), lds, st, sph, fa, ta, lp);
 }
 
-template <int MODE, bool NS8>
+template <int MODE, int SC>
 void launch_frame_g(int group, bool retire, dim3 grid, size_t lds, hipStream_t st, const float *sph,
                     const FrameArgs &fa, const TraceArgs &ta, const LeafProg &lp) {
-    if (group == 8) launch_frame<MODE, NS8, 8>(retire, grid, lds, st, sph, fa, ta, lp);
-    else launch_frame<MODE, NS8, 1>(retire, grid, lds, st, sph, fa, ta, lp);
+    if (group == 8) launch_frame<MODE, SC, 8>(retire, grid, lds, st, sph, fa, ta, lp);
+    else launch_frame<MODE, SC, 1>(retire, grid, lds, st, sph, fa, ta, lp);
 }
 
 } // namespace
@@ -1055,12 +1066,15 @@ int render_do_ex(const apt_render_params *p, void *stream, const float *rays, co
     const TraceArgs ta = make_trace_args(p);
     const bool retire = p->flags & APT_FLAG_RETIRE;
     const dim3 grid((unsigned)blocks);
+    const int sck = ns8 ? kScene8 : (ta.grid ? kSceneGrid : kSceneTiles);
     if (p->mode == APT_MODE_ORACLE) {
-        if (ns8) launch_paths<kModeOracle, true>(retire, grid, st, rays, spheres, colors, n, b, c, ta);
-        else launch_paths<kModeOracle, false>(retire, grid, st, rays, spheres, colors, n, b, c, ta);
+        if (sck == kScene8) launch_paths<kModeOracle, kScene8>(retire, grid, st, rays, spheres, colors, n, b, c, ta);
+        else if (sck == kSceneGrid) launch_paths<kModeOracle, kSceneGrid>(retire, grid, st, rays, spheres, colors, n, b, c, ta);
+        else launch_paths<kModeOracle, kSceneTiles>(retire, grid, st, rays, spheres, colors, n, b, c, ta);
     } else {
-        if (ns8) launch_paths<kModeKernel, true>(retire, grid, st, rays, spheres, colors, n, b, c, ta);
-        else launch_paths<kModeKernel, false>(retire, grid, st, rays, spheres, colors, n, b, c, ta);
+        if (sck == kScene8) launch_paths<kModeKernel, kScene8>(retire, grid, st, rays, spheres, colors, n, b, c, ta);
+        else if (sck == kSceneGrid) launch_paths<kModeKernel, kSceneGrid>(retire, grid, st, rays, spheres, colors, n, b, c, ta);
+        else launch_paths<kModeKernel, kSceneTiles>(retire, grid, st, rays, spheres, colors, n, b, c, ta);
     }
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? APT_OK : hip_fail(e);
@@ -1098,12 +1112,15 @@ int render_frame(const apt_render_params *p, void *stream, const float *spheres,
     size_t lds = lp.nleaves > 1 ? (size_t)kMaxStack * 3 * kStackSlots * sizeof(float) : 0;
     if (retire && ns8 && group == 8) lds += (size_t)(kBlock / 64) * 3 * 8 * lp.maxleaf * sizeof(float); // colour queue
     const dim3 grid((unsigned)blocks);
+    const int sck = ns8 ? kScene8 : (ta.grid ? kSceneGrid : kSceneTiles);
     if (p->mode == APT_MODE_ORACLE) {
-        if (ns8) launch_frame_g<kModeOracle, true>(group, retire, grid, lds, st, spheres, fa, ta, lp);
-        else launch_frame_g<kModeOracle, false>(group, retire, grid, lds, st, spheres, fa, ta, lp);
+        if (sck == kScene8) launch_frame_g<kModeOracle, kScene8>(group, retire, grid, lds, st, spheres, fa, ta, lp);
+        else if (sck == kSceneGrid) launch_frame_g<kModeOracle, kSceneGrid>(group, retire, grid, lds, st, spheres, fa, ta, lp);
+        else launch_frame_g<kModeOracle, kSceneTiles>(group, retire, grid, lds, st, spheres, fa, ta, lp);
     } else {
-        if (ns8) launch_frame_g<kModeKernel, true>(group, retire, grid, lds, st, spheres, fa, ta, lp);
-        else launch_frame_g<kModeKernel, false>(group, retire, grid, lds, st, spheres, fa, ta, lp);
+        if (sck == kScene8) launch_frame_g<kModeKernel, kScene8>(group, retire, grid, lds, st, spheres, fa, ta, lp);
+        else if (sck == kSceneGrid) launch_frame_g<kModeKernel, kSceneGrid>(group, retire, grid, lds, st, spheres, fa, ta, lp);
+        else launch_frame_g<kModeKernel, kSceneTiles>(group, retire, grid, lds, st, spheres, fa, ta, lp);
     }
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? APT_OK : hip_fail(e);
