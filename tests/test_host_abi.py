@@ -126,3 +126,20 @@ def test_grid_builder_layout(apt):
     geom = g[off_geom:off_geom + 4 * ns].view(np.float32).reshape(ns, 4)
     tab = scene[:10 * ns].reshape(10, ns)
     assert np.array_equal(geom[:, 0], tab[1]) and np.array_equal(geom[:, 3], tab[0])
+
+
+def test_missing_library_fails_loudly(apt, monkeypatch, tmp_path):
+    """No silent fallback: without librender_mi355x.so every entry raises AptError."""
+    from ascendpathtracing_amd import _lib, gen_data
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "librender_mi355x.so"))
+    with pytest.raises(apt.AptError, match="is missing"):
+        gen_data.gen_spheres()
+    with pytest.raises(apt.AptError, match="is missing"):
+        apt.default_params()
+
+
+def test_run_sh_refuses_cpu_mode():
+    import subprocess
+    r = subprocess.run(["bash", os.path.join(ROOT, "run.sh"), "-r", "cpu", "-v", "Ascend310P1"], capture_output=True, text=True)
+    assert r.returncode != 0 and "no CPU fallback" in r.stdout
