@@ -4,7 +4,9 @@ reference's own pipeline, GPU vs CPU restatement, every one of the 530,841,600 p
   gen_rays (MT19937, seed 0)  : device (checkpointed stream) vs the library's sequential host generator
   render (O-mode = NumPy oracle arithmetic, and K-mode)       : device vs oracle.render_paths (all host threads)
   decode_color                                               : device vs oracle.decode_color
-Checker code (oracle) is used here as the checker only.  ~2-3 minutes, ~40 GB of host memory."""
+Checker code (oracle) is used here as the checker only.  ~70 s on 128 host threads, ~40 GB of host memory.
+Run directly (python tests/full_size_c2_parity.py) or through pytest with APT_FULL_PARITY=1
+(tests/test_gpu_parity.py::test_full_size_c2_parity); the round-1 log is profiles/r01_c2_full_parity.log."""
 import hashlib, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
