@@ -433,6 +433,70 @@ __global__ __launch_bounds__(kBlock) void render_paths_kernel(const float *__res
     count_traced(ta, valid ? traced : 0);
 }
 
+// ---- kernel: rays from a buffer, with active-ray compaction (APT_FLAG_RETIRE, Ns == 8) ------------
+// Buffer mode has no ordering constraint on its outputs (colour p is stored to colors[p]), so the
+// wave-level queue is simple: every wave owns kQueueChunk consecutive paths; a lane whose path is
+// finished (alive bit cleared, throughput zero, depth reached) takes the next unissued path of the
+// chunk -- ballot of the idle lanes, mbcnt prefix rank, p = next + rank -- and loads its ray.
+constexpr uint32_t kQueueChunk = 64 * 16;
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void render_paths_queue_kernel(const float *__restrict__ rays,
+                                                                    const float *__restrict__ sph,
+                                                                    float *__restrict__ colors, uint64_t n_total,
+                                                                    uint64_t begin, uint64_t count, TraceArgs ta) {
+    __shared__ float4 tab[16];
+    Scene8 sc;
+    load_scene8(sph, sc, tab);
+    const Gain3 gain = load_gain(sph, ta);
+    const uint64_t wave = (uint64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    uint64_t next = wave * kQueueChunk;                         // wave-uniform
+    const uint64_t end = min(count, next + kQueueChunk);
+    uint32_t depth_left = 0, traced = 0;
+    uint64_t cur = 0, cur_key = 0;
+    PathState s;
+    path_init(s, 0.f, 0.f, 0.f, 0.f, 0.f, 1.f);
+    for (;;) {
+        const bool want = depth_left == 0;
+        const unsigned long long wants = __ballot(want);
+        if (next < end && wants) {
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(wants >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)wants, 0u));
+            const uint64_t remaining = end - next;
+            if (want && rank < remaining) {
+                cur = begin + next + rank;
+                path_init(s, rays[cur], rays[n_total + cur], rays[2 * n_total + cur], rays[3 * n_total + cur],
+                          rays[4 * n_total + cur], rays[5 * n_total + cur]);
+                depth_left = ta.depth;
+                if (ta.rr_start) cur_key = rr_path_key(ta.seed, cur);
+                if (ta.depth == 0) { colors[cur] = gain.r; colors[n_total + cur] = gain.g; colors[2 * n_total + cur] = gain.b; }
+            }
+            next += min((uint64_t)__popcll(wants), remaining);
+        }
+        const bool active = depth_left != 0;
+        if (!__any(active)) {
+            if (next >= end) break;
+            continue;
+        }
+        PathState nx;
+        bool redo = bounce_ns8<MODE, true>(sc, tab, s, nx, ta);
+        redo = redo && active;
+        if (__builtin_expect(__any(redo), 0)) { // exact re-run, see trace_ns8
+            asm volatile("" ::: "memory");
+            (void)bounce_ns8<MODE, false>(sc, tab, s, nx, ta);
+        }
+        if (ta.rr_start && ta.depth - depth_left + 1 >= ta.rr_start) russian_roulette(nx, cur_key, ta.depth - depth_left);
+        s = nx;
+        traced += active ? 1u : 0u;
+        depth_left -= active ? 1u : 0u;
+        if (active && (depth_left == 0 || path_finished(s))) {
+            depth_left = 0;
+            colors[cur] = s.rx * gain.r;
+            colors[n_total + cur] = s.ry * gain.g;
+            colors[2 * n_total + cur] = s.rz * gain.b;
+        }
+    }
+    count_traced(ta, traced);
+}
+
 // ---- kernel: fused frame ----------------------------------------------------------------
 struct FrameArgs {
     Camera cam;
@@ -1067,7 +1131,12 @@ int render_do_ex(const apt_render_params *p, void *stream, const float *rays, co
     const bool retire = p->flags & APT_FLAG_RETIRE;
     const dim3 grid((unsigned)blocks);
     const int sck = ns8 ? kScene8 : (ta.grid ? kSceneGrid : kSceneTiles);
-    if (p->mode == APT_MODE_ORACLE) {
+    if (retire && ns8) { // wave-level queue: one wave per kQueueChunk consecutive paths
+        const uint64_t waves = (c + kQueueChunk - 1) / kQueueChunk;
+        const dim3 qgrid((unsigned)((waves + kBlock / 64 - 1) / (kBlock / 64)));
+        if (p->mode == APT_MODE_ORACLE) hipLaunchKernelGGL((render_paths_queue_kernel<kModeOracle>), qgrid, dim3(kBlock), 0, st, rays, spheres, colors, n, b, c, ta);
+        else hipLaunchKernelGGL((render_paths_queue_kernel<kModeKernel>), qgrid, dim3(kBlock), 0, st, rays, spheres, colors, n, b, c, ta);
+    } else if (p->mode == APT_MODE_ORACLE) {
         if (sck == kScene8) launch_paths<kModeOracle, kScene8>(retire, grid, st, rays, spheres, colors, n, b, c, ta);
         else if (sck == kSceneGrid) launch_paths<kModeOracle, kSceneGrid>(retire, grid, st, rays, spheres, colors, n, b, c, ta);
         else launch_paths<kModeOracle, kSceneTiles>(retire, grid, st, rays, spheres, colors, n, b, c, ta);

@@ -68,8 +68,11 @@ colors = torch.empty(3 * p.num_paths, device="cuda")
 ms_gen = timeit(lambda: gen_data.gen_rays_device(1920, 1080, 64, checkpoints=ck, stride=64), 2)
 ms_ren = timeit(lambda: render.render_do_ex(p, None, rays, sph8, colors), 2)
 ms_dec = timeit(lambda: render.decode_color_device(p, colors), 2)
+pq = p.copy(flags=apt.APT_FLAG_RETIRE)
+ms_ren_q = timeit(lambda: render.render_do_ex(pq, None, rays, sph8, colors), 2)
 report("C2 exact reference pipeline on device (MT19937 rays, buffer mode, O-mode)", ms_gen + ms_ren + ms_dec,
        p.num_paths * 8, 8, {"gen_rays_ms": round(ms_gen, 2), "render_ms": round(ms_ren, 2), "decode_ms": round(ms_dec, 2),
+                            "render_ms_with_compaction": round(ms_ren_q, 2),
                             "host_checkpoint_seconds_once": round(t_ck, 2), "hbm_GB": round((9 * 4 * p.num_paths) / 1e9, 1)})
 del rays, colors, ck
 torch.cuda.empty_cache()
