@@ -343,7 +343,7 @@ APT_HD void test_scene_sphere(float cx, float cy, float cz, float r2, float ox, 
 }
 
 // ---- ray generation (all float64, cast to float32 at the end: gen_data.py:71) ---------
-struct Camera { double pos[3], g[3], cx[3], cy[3]; };
+struct Camera { double pos[3], g[3], cx[3], cy[3], inv_w, inv_h; }; // inv_*: host-made RN(1/w), RN(1/h)
 
 APT_HD double norm3(double x, double y, double z) { // np.linalg.norm: sqrt(ddot); ddot is an FMA chain
     double acc = x * x;
@@ -364,6 +364,8 @@ inline void camera_init(Camera &c, uint32_t w, uint32_t h) { // gen_data.py:24-3
     cr[2] = c.cx[0] * c.g[1] - c.cx[1] * c.g[0];
     const double cn = norm3(cr[0], cr[1], cr[2]);
     for (int i = 0; i < 3; ++i) c.cy[i] = cr[i] / cn * 0.5135;
+    c.inv_w = 1.0 / (double)w; // correctly rounded (IEEE division on the host); used by the device's fast quotients
+    c.inv_h = 1.0 / (double)h;
 }
 
 APT_HD double tent(double u) { // gen_data.py:37-40
@@ -373,13 +375,55 @@ APT_HD double tent(double u) { // gen_data.py:37-40
 
 struct Ray { float ox, oy, oz, dx, dy, dz; };
 
+#if defined(__HIP_DEVICE_COMPILE__)
+// Correctly rounded float64 quotients without the full division expansion (v_div_scale x2, v_rcp_f64,
+// two Newton steps, mul, fma, v_div_fmas, v_div_fixup: ~56 cycles each, five per ray).
+//   div_by_rn_reciprocal: y = RN(1/b) exactly (made on the host) -> q = a*y, r = fma(-b,q,a), q' = fma(r,y,q)
+//   is RN(a/b) (Markstein): the same final correction step hipcc's own lowering ends with.
+//   refined_reciprocal: v_rcp_f64 + two Newton steps = the reciprocal hipcc's lowering uses; one such
+//   reciprocal serves the three quotients by the norm.
+// Valid while nothing is scaled: operands and quotients far from the ends of the exponent range and the
+// numerator not -0; otherwise the whole wave redoes the quotients with '/'.  Validated bit for bit against true IEEE division on the CPU
+// by the device-vs-oracle ray tests, incl. all 530,841,600 paths of config C2.
+__device__ __forceinline__ double div_by_rn_reciprocal(double a, double b, double y) {
+    const double q = a * y;
+    const double r = fma(-b, q, a);
+    return fma(r, y, q);
+}
+__device__ __forceinline__ double refined_reciprocal(double b) {
+    double y = __builtin_amdgcn_rcp(b);
+    double e = fma(-b, y, 1.0);
+    y = fma(y, e, y);
+    e = fma(-b, y, 1.0);
+    return fma(y, e, y);
+}
+// Numerators here are bounded above by construction (|x| <= w+1 resp. |d| < 3 with u in [0,1) and a
+// finite camera), so only the lower end needs a run-time check: zero (its sign would matter), denormal or
+// absurdly small numerators send the wave to the plain '/'.  (A numerator is 0 only for a handful of
+// exact jitter values, probability ~2^-52 per path.)
+__device__ __forceinline__ bool quotient_operands_ok(double a, double b) { return fmin(fabs(a), fabs(b)) >= 0x1p-60; }
+#endif
+
 // Outputs are six scalar references on purpose: an aggregate result gets its stores merged into
 // vector stores to a stack slot that SROA can then no longer promote (it ended up in scratch).
 APT_HD void camera_ray(const Camera &c, uint32_t w, uint32_t h, uint32_t i, uint32_t j, uint32_t sy, uint32_t sx,
                        double u1, double u2, float &rox, float &roy, float &roz, float &rdx, float &rdy, float &rdz) {
     double ddx = tent(u1), ddy = tent(u2);
-    double a = (((double)sx + 0.5 + ddx) / 2 + (double)i) / (double)w - 0.5; // :41
-    double b = (((double)sy + 0.5 + ddy) / 2 + (double)j) / (double)h - 0.5; // :42
+    const double xa = ((double)sx + 0.5 + ddx) / 2 + (double)i, xb = ((double)sy + 0.5 + ddy) / 2 + (double)j;
+#if defined(__HIP_DEVICE_COMPILE__)
+    const bool ok1 = quotient_operands_ok(xa, xb);
+    double a, b;
+    if (__builtin_expect(__all(ok1), 1)) {
+        a = div_by_rn_reciprocal(xa, (double)w, c.inv_w) - 0.5;                  // :41
+        b = div_by_rn_reciprocal(xb, (double)h, c.inv_h) - 0.5;                  // :42
+    } else {
+        a = xa / (double)w - 0.5;
+        b = xb / (double)h - 0.5;
+    }
+#else
+    double a = xa / (double)w - 0.5;                                             // :41
+    double b = xb / (double)h - 0.5;                                             // :42
+#endif
     double d0 = (c.cx[0] * a + c.cy[0] * b) + c.g[0];
     double d1 = (c.cx[1] * a + c.cy[1] * b) + c.g[1];
     double d2 = (c.cx[2] * a + c.cy[2] * b) + c.g[2];
@@ -387,6 +431,16 @@ APT_HD void camera_ray(const Camera &c, uint32_t w, uint32_t h, uint32_t i, uint
     rox = (float)(c.pos[0] + d0 * 140);                                      // :45
     roy = (float)(c.pos[1] + d1 * 140);
     roz = (float)(c.pos[2] + d2 * 140);
+#if defined(__HIP_DEVICE_COMPILE__)
+    const bool ok2 = quotient_operands_ok(fmin(fabs(d0), fabs(d1)), d2) && n <= 0x1p60; // n >= max|d_i| >= 2^-60; n <= 2^60 also rejects NaN/inf
+    if (__builtin_expect(__all(ok2), 1)) {
+        const double y = refined_reciprocal(n);
+        rdx = (float)div_by_rn_reciprocal(d0, n, y);                         // :46
+        rdy = (float)div_by_rn_reciprocal(d1, n, y);
+        rdz = (float)div_by_rn_reciprocal(d2, n, y);
+        return;
+    }
+#endif
     rdx = (float)(d0 / n);                                                   // :46
     rdy = (float)(d1 / n);
     rdz = (float)(d2 / n);

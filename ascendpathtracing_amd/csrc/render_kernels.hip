@@ -520,10 +520,10 @@ __global__ __launch_bounds__(kBlock, (RETIRE && SC == kScene8 && GROUP == 8) ? 5
     extern __shared__ float dyn_lds[];
     float *stack_lds = dyn_lds;                                            // [kMaxStack][3][kStackSlots] when lp.nleaves > 1
     float *queue_lds = dyn_lds + (lp.nleaves > 1 ? kMaxStack * 3 * kStackSlots : 0); // [waves][3][8*maxleaf] (refill)
-    // The camera frame (12 doubles) is only needed by ray-generate; parked in LDS it does not
-    // occupy 24 SGPRs across the bounce loop (they spilled to VGPR lanes otherwise).
+    // The camera frame (14 doubles) is only needed by ray-generate; parked in LDS it does not
+    // occupy 28 SGPRs across the bounce loop (they spilled to VGPR lanes otherwise).
     __shared__ Camera cam;
-    if (threadIdx.x < 12) (&cam.pos[0])[threadIdx.x] = (&fa.cam.pos[0])[threadIdx.x];
+    if (threadIdx.x < sizeof(Camera) / sizeof(double)) (&cam.pos[0])[threadIdx.x] = (&fa.cam.pos[0])[threadIdx.x];
     Scene8 sc;
     if (NS8) load_scene8(sph, sc, tab);
     else __syncthreads();
