@@ -345,12 +345,12 @@ APT_HD void test_scene_sphere(float cx, float cy, float cz, float r2, float ox, 
 // ---- ray generation (all float64, cast to float32 at the end: gen_data.py:71) ---------
 struct Camera { double pos[3], g[3], cx[3], cy[3], inv_w, inv_h; }; // inv_*: host-made RN(1/w), RN(1/h)
 
-APT_HD double norm3(double x, double y, double z) { // np.linalg.norm: sqrt(ddot); ddot is an FMA chain
+APT_HD double norm3_sq(double x, double y, double z) { // np.linalg.norm: sqrt(ddot); ddot is an FMA chain
     double acc = x * x;
     acc = fma(y, y, acc);
-    acc = fma(z, z, acc);
-    return sqrt(acc);
+    return fma(z, z, acc);
 }
+APT_HD double norm3(double x, double y, double z) { return sqrt(norm3_sq(x, y, z)); }
 
 inline void camera_init(Camera &c, uint32_t w, uint32_t h) { // gen_data.py:24-30
     c.pos[0] = 50; c.pos[1] = 52; c.pos[2] = 295.6;
@@ -368,9 +368,40 @@ inline void camera_init(Camera &c, uint32_t w, uint32_t h) { // gen_data.py:24-3
     c.inv_h = 1.0 / (double)h;
 }
 
-APT_HD double tent(double u) { // gen_data.py:37-40
-    double r = 2 * u;
-    return (r < 1) ? sqrt(r) - 1 : 1 - sqrt(2 - r);
+#if defined(__HIP_DEVICE_COMPILE__)
+// float64 sqrt for ray-generate: the core of hipcc's own expansion (v_rsq_f64, coupled Goldschmidt
+// steps, two residual corrections) without its ldexp pre/post-scaling (only needed below 2^-767) and
+// class test (zero/inf).  Arguments here lie in {0} u [2^-53, 2]; zero or anything below 2^-700 sends
+// the wave to sqrt().  Same operations in the same order as the compiler's sequence, so the same bits
+// (checked against the CPU's correctly rounded sqrt by the ray tests, incl. 530 M paths of C2).
+__device__ __forceinline__ double sqrt_f64_core(double x) {
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = y * 0.5;
+    const double r = fma(-h, g, 0.5);
+    g = fma(g, r, g);
+    double d = fma(-g, g, x);
+    h = fma(h, r, h);
+    g = fma(d, h, g);
+    d = fma(-g, g, x);
+    return fma(d, h, g);
+}
+__device__ __forceinline__ double sqrt_f64_fast(double x) {
+    if (__builtin_expect(__all(x >= 0x1p-700 && x <= 0x1p700), 1)) return sqrt_f64_core(x);
+    return sqrt(x);
+}
+#define APT_SQRT64(x) sqrt_f64_fast(x)
+#else
+#define APT_SQRT64(x) sqrt(x)
+#endif
+
+// gen_data.py:37-40: dx = sqrt(r)-1 if r < 1 else 1-sqrt(2-r).  Written branch-free (one sqrt of the
+// selected argument, then the selected combination): the same operations on the same values as the
+// two-armed form, without executing both arms when the lanes of a wave disagree.
+APT_HD double tent(double u) {
+    const double r = 2 * u;
+    const bool lower = r < 1;
+    const double q = APT_SQRT64(lower ? r : 2 - r);
+    return lower ? q - 1 : 1 - q;
 }
 
 struct Ray { float ox, oy, oz, dx, dy, dz; };
@@ -427,7 +458,7 @@ APT_HD void camera_ray(const Camera &c, uint32_t w, uint32_t h, uint32_t i, uint
     double d0 = (c.cx[0] * a + c.cy[0] * b) + c.g[0];
     double d1 = (c.cx[1] * a + c.cy[1] * b) + c.g[1];
     double d2 = (c.cx[2] * a + c.cy[2] * b) + c.g[2];
-    double n = norm3(d0, d1, d2);
+    double n = APT_SQRT64(norm3_sq(d0, d1, d2));
     rox = (float)(c.pos[0] + d0 * 140);                                      // :45
     roy = (float)(c.pos[1] + d1 * 140);
     roz = (float)(c.pos[2] + d2 * 140);
