@@ -45,6 +45,10 @@ constexpr int kBlock = 256;      // 4 waves
 constexpr int kScene8 = 0, kSceneTiles = 1, kSceneGrid = 2; // template parameter SC: how the scene reaches the lanes
 constexpr int kTile = 1024;      // spheres per LDS tile (16 KB)
 constexpr int kMaxLeaves = 64;   // pairwise-sum leaves -> samples <= 8192
+#ifndef APT_GRID_WAVES
+#define APT_GRID_WAVES 8 // min waves per SIMD requested for the grid-walk kernels: the walk is latency bound
+                         // (dependent cell -> item loads), measured 464 / 371 / 334 / 311 / 302 ms at 3 / 4 / 5 / 6 / 8 waves
+#endif
 #ifndef APT_FULL_WAVES
 #define APT_FULL_WAVES 1 // min waves per SIMD requested for the full-trace frame kernel (A/B knob)
 #endif
@@ -354,12 +358,13 @@ __device__ __forceinline__ uint32_t trace_grid(const float *__restrict__ sph, co
                 }
             }
         }
-        const uint32_t g = (idx < 0) ? ns - 1 : (uint32_t)idx;
-        const float4 gc = geom[g];
-        PathState n = s;
-        shade_and_reflect<MODE>(n, tmin, gc.x, gc.y, gc.z, colx[g], coly[g], colz[g], idx == ta.light);
-        if (ta.rr_start && d + 1 >= ta.rr_start) russian_roulette(n, rr_key, d);
-        if (!fin) { s = n; ++traced; }
+        if (!fin) { // per-lane code anyway: shade in place (no second copy of the path state in registers)
+            const uint32_t g = (idx < 0) ? ns - 1 : (uint32_t)idx;
+            const float4 gc = geom[g];
+            shade_and_reflect<MODE>(s, tmin, gc.x, gc.y, gc.z, colx[g], coly[g], colz[g], idx == ta.light);
+            if (ta.rr_start && d + 1 >= ta.rr_start) russian_roulette(s, rr_key, d);
+            ++traced;
+        }
     }
     if (ta.traced) { // statistics: cells visited / candidates tested (per lane, summed over the wave)
         unsigned long long c = n_cells, t = n_tests;
@@ -405,7 +410,7 @@ __device__ __forceinline__ void count_traced(const TraceArgs &ta, uint32_t trace
 
 // ---- kernel: rays from a buffer ---------------------------------------------------------
 template <int MODE, int SC, bool RETIRE>
-__global__ __launch_bounds__(kBlock) void render_paths_kernel(const float *__restrict__ rays,
+__global__ __launch_bounds__(kBlock, SC == kSceneGrid ? APT_GRID_WAVES : 1) void render_paths_kernel(const float *__restrict__ rays,
                                                               const float *__restrict__ sph,
                                                               float *__restrict__ colors, uint64_t n_total,
                                                               uint64_t begin, uint64_t count, TraceArgs ta) {
@@ -512,7 +517,7 @@ struct FrameArgs {
 // a 3-step butterfly and no shared memory.  GROUP == 1 serves samples < 8 (numpy sums
 // those sequentially).
 template <int MODE, int SC, int GROUP, bool RETIRE>
-__global__ __launch_bounds__(kBlock, (RETIRE && SC == kScene8 && GROUP == 8) ? 5 : APT_FULL_WAVES) void render_frame_kernel(const float *__restrict__ sph, FrameArgs fa,
+__global__ __launch_bounds__(kBlock, (RETIRE && SC == kScene8 && GROUP == 8) ? 5 : (SC == kSceneGrid ? APT_GRID_WAVES : APT_FULL_WAVES)) void render_frame_kernel(const float *__restrict__ sph, FrameArgs fa,
                                                               TraceArgs ta, LeafProg lp) {
     constexpr bool NS8 = SC == kScene8;
     __shared__ float4 tab[16];
