@@ -143,3 +143,48 @@ def test_run_sh_refuses_cpu_mode():
     import subprocess
     r = subprocess.run(["bash", os.path.join(ROOT, "run.sh"), "-r", "cpu", "-v", "Ascend310P1"], capture_output=True, text=True)
     assert r.returncode != 0 and "no CPU fallback" in r.stdout
+
+
+def test_mt19937_checkpoints_match_numpy_generator_state(apt):
+    """apt_mt19937_checkpoints_host: checkpoint i must be NumPy's legacy MT19937 key array after
+    (i*stride + 1) * 624 words have been drawn (np.random.seed / rand of gen_data.py:438,37)."""
+    for seed in (0, 12345):
+        ck = apt.gen_data.mt19937_checkpoints(156 * 10, seed=seed, stride=3)      # 10 blocks -> checkpoints 0, 3, 6, 9
+        assert ck.shape == (4, 624)
+        rs = np.random.RandomState(seed)
+        for i, blk in enumerate((0, 3, 6, 9)):
+            rs2 = np.random.RandomState(seed)
+            rs2.random_sample((blk + 1) * 312)                                   # 2 words per double
+            key, pos = rs2.get_state()[1], rs2.get_state()[2]
+            assert pos == 624 and np.array_equal(ck[i], key), (seed, blk)
+    with pytest.raises(apt.AptError):
+        apt._lib.check(apt._lib.lib().apt_mt19937_checkpoints_host(0, 0, 1, None), "checkpoints")
+
+
+def test_c_abi_argument_validation_needs_no_gpu(apt):
+    """Every device entry validates its arguments before touching HIP: the error codes of
+    include/render_mi355x.h come back on a machine without a GPU as well."""
+    L = apt._lib.lib()
+    p = apt.default_params()
+    one = ctypes.c_void_p(16)      # never dereferenced: validation fails first
+    bad = apt.default_params(); bad.struct_size = 8
+    assert L.render_do_ex(ctypes.byref(bad), None, one, one, one) == 2                      # APT_ERR_STRUCT
+    assert L.render_do_ex(None, None, one, one, one) == 1                                   # APT_ERR_ARG
+    assert L.render_do_ex(ctypes.byref(p), None, None, one, one) == 1
+    z = apt.make_params(0, 16, 1)
+    assert L.render_do_ex(ctypes.byref(z), None, one, one, one) == 1
+    s0 = apt.make_params(16, 16, 1, num_spheres=8, light_index=9)
+    assert L.render_do_ex(ctypes.byref(s0), None, one, one, one) == 3                       # APT_ERR_SCENE
+    assert b"light_index" in L.apt_last_error()
+    rng = apt.make_params(16, 16, 1, path_begin=1000, path_count=100)
+    assert L.render_do_ex(ctypes.byref(rng), None, one, one, one) == 1
+    assert L.render_frame(ctypes.byref(p), None, one, ctypes.c_uint64(0), ctypes.c_uint64(10 ** 9), one, None) == 1
+    big = apt.make_params(16, 16, 1 << 20)                                                  # pairwise plan too long
+    assert L.render_frame(ctypes.byref(big), None, one, ctypes.c_uint64(0), ctypes.c_uint64(1), one, None) == 1
+    em = apt.make_params(16, 16, 1, light_index=-1, flags=apt.APT_FLAG_EMISSION)
+    assert L.render_do_ex(ctypes.byref(em), None, one, one, one) == 3
+    assert L.apt_set_refill_lanes(0) == 1 and L.apt_set_refill_lanes(65) == 1 and L.apt_set_refill_lanes(32) == 0
+    assert L.apt_gen_rays_mt_device(ctypes.byref(p), None, one, ctypes.c_uint32(4), ctypes.c_uint64(0), one) == 1   # too few checkpoints
+    assert L.apt_build_grid_host(None, 8, None, None) == 1
+    e = apt.make_params(16, 16, 1, path_begin=1024, path_count=0)                           # empty range is a no-op, not an error
+    assert L.render_do_ex(ctypes.byref(e), None, one, one, one) == 0
