@@ -42,6 +42,17 @@ for mode, name in ((apt.APT_MODE_KERNEL, "K"), (apt.APT_MODE_ORACLE, "O")):
     colors = torch.empty(3 * p.num_paths, device="cuda")
     ms = timeit(lambda: render.render_do_ex(p, None, rays, sph8, colors), args.reps)
     report(f"C1 256x256 4spp D4 buffer mode {name}-mode", ms, p.num_paths * 4, 8)
+# C1 with host buffers: pinned rays H2D + render_do + colours D2H (what src/main.cpp:68-77 does around the launch)
+p = apt.make_params(256, 256, 1, depth=4)
+rays_h = torch.from_numpy(gen_data.gen_rays(256, 256, 1, seed=0).ravel().copy()).pin_memory()
+cols_h = torch.empty(3 * p.num_paths, dtype=torch.float32).pin_memory()
+rays_d = torch.empty_like(rays_h, device="cuda"); cols_d = torch.empty(3 * p.num_paths, device="cuda")
+def roundtrip():
+    rays_d.copy_(rays_h, non_blocking=True)
+    render.render_do_ex(p, None, rays_d, sph8, cols_d)
+    cols_h.copy_(cols_d, non_blocking=True)
+ms = timeit(roundtrip, 5)
+report("C1 256x256 4spp D4 buffer mode incl. PCIe (6.3 MB H2D + 3.1 MB D2H, pinned)", ms, p.num_paths * 4, 8)
 # C2 in O-mode (the NumPy oracle's arithmetic: float64-accumulated dot products in the shading step)
 p = apt.make_params(1920, 1080, 64, depth=8, mode=apt.APT_MODE_ORACLE)
 ms = timeit(lambda: render.render_frame(p, sph8), args.reps)
