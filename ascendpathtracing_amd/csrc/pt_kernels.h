@@ -1,0 +1,575 @@
+// pt_kernels.h -- the __global__ kernels of librender_mi355x.so (included by render_kernels.hip only):
+// buffer-mode render (+ its compaction variant), fused frame, first-hit mode, device gen_rays (counter
+// RNG and the reference's MT19937 stream), device decode_color, and the arithmetic self-tests.
+#pragma once
+#include "pt_trace.h"
+
+namespace {
+
+// ---- kernel: rays from a buffer ---------------------------------------------------------
+template <int MODE, int SC, bool RETIRE>
+__global__ __launch_bounds__(kBlock, SC == kSceneGrid ? APT_GRID_WAVES : 1) void render_paths_kernel(const float *__restrict__ rays,
+                                                              const float *__restrict__ sph,
+                                                              float *__restrict__ colors, uint64_t n_total,
+                                                              uint64_t begin, uint64_t count, TraceArgs ta) {
+    constexpr bool NS8 = SC == kScene8;
+    __shared__ float4 tab[16];
+    __shared__ float4 tile[SC == kSceneTiles ? kTile : 1];
+    Scene8 sc;
+    if (NS8) load_scene8(sph, sc, tab);
+    const uint64_t local = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    const bool valid = local < count;
+    const uint64_t p = begin + (valid ? local : 0);
+    PathState s;                                          // CopyIn: render.cpp:82-101
+    path_init(s, rays[p], rays[n_total + p], rays[2 * n_total + p], rays[3 * n_total + p], rays[4 * n_total + p],
+              rays[5 * n_total + p]);
+    uint32_t traced;
+    if (SC == kScene8) traced = trace_ns8<MODE, RETIRE>(sc, tab, s, valid, ta, p);
+    else if (SC == kSceneGrid) traced = trace_grid<MODE, RETIRE>(sph, ta.grid, s, valid, ta, p);
+    else traced = trace_dyn<MODE, RETIRE>(sph, tile, s, valid, ta, p);
+    if (valid) {                                          // render.cpp:194-196, CopyOut :210-223
+        const Gain3 gain = load_gain(sph, ta);
+        colors[p] = s.rx * gain.r;
+        colors[n_total + p] = s.ry * gain.g;
+        colors[2 * n_total + p] = s.rz * gain.b;
+    }
+    count_traced(ta, valid ? traced : 0);
+}
+
+// ---- kernel: rays from a buffer, with active-ray compaction (APT_FLAG_RETIRE, Ns == 8) ------------
+// Buffer mode has no ordering constraint on its outputs (colour p is stored to colors[p]), so the
+// wave-level queue is simple: every wave owns kQueueChunk consecutive paths; a lane whose path is
+// finished (alive bit cleared, throughput zero, depth reached) takes the next unissued path of the
+// chunk -- ballot of the idle lanes, mbcnt prefix rank, p = next + rank -- and loads its ray.
+constexpr uint32_t kQueueChunk = 64 * 16;
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void render_paths_queue_kernel(const float *__restrict__ rays,
+                                                                    const float *__restrict__ sph,
+                                                                    float *__restrict__ colors, uint64_t n_total,
+                                                                    uint64_t begin, uint64_t count, TraceArgs ta) {
+    __shared__ float4 tab[16];
+    Scene8 sc;
+    load_scene8(sph, sc, tab);
+    const Gain3 gain = load_gain(sph, ta);
+    const uint64_t wave = (uint64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    uint64_t next = wave * kQueueChunk;                         // wave-uniform
+    const uint64_t end = min(count, next + kQueueChunk);
+    uint32_t depth_left = 0, traced = 0;
+    uint64_t cur = 0, cur_key = 0;
+    PathState s;
+    path_init(s, 0.f, 0.f, 0.f, 0.f, 0.f, 1.f);
+    for (;;) {
+        const bool want = depth_left == 0;
+        const unsigned long long wants = __ballot(want);
+        if (next < end && wants) {
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(wants >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)wants, 0u));
+            const uint64_t remaining = end - next;
+            if (want && rank < remaining) {
+                cur = begin + next + rank;
+                path_init(s, rays[cur], rays[n_total + cur], rays[2 * n_total + cur], rays[3 * n_total + cur],
+                          rays[4 * n_total + cur], rays[5 * n_total + cur]);
+                depth_left = ta.depth;
+                if (ta.rr_start) cur_key = rr_path_key(ta.seed, cur);
+                if (ta.depth == 0) { colors[cur] = gain.r; colors[n_total + cur] = gain.g; colors[2 * n_total + cur] = gain.b; }
+            }
+            next += min((uint64_t)__popcll(wants), remaining);
+        }
+        const bool active = depth_left != 0;
+        if (!__any(active)) {
+            if (next >= end) break;
+            continue;
+        }
+        PathState nx;
+        bool redo = bounce_ns8<MODE, true>(sc, tab, s, nx, ta);
+        redo = redo && active;
+        if (__builtin_expect(__any(redo), 0)) { // exact re-run, see trace_ns8
+            asm volatile("" ::: "memory");
+            (void)bounce_ns8<MODE, false>(sc, tab, s, nx, ta);
+        }
+        if (ta.rr_start && ta.depth - depth_left + 1 >= ta.rr_start) russian_roulette(nx, cur_key, ta.depth - depth_left);
+        s = nx;
+        traced += active ? 1u : 0u;
+        depth_left -= active ? 1u : 0u;
+        if (active && (depth_left == 0 || path_finished(s))) {
+            depth_left = 0;
+            colors[cur] = s.rx * gain.r;
+            colors[n_total + cur] = s.ry * gain.g;
+            colors[2 * n_total + cur] = s.rz * gain.b;
+        }
+    }
+    count_traced(ta, traced);
+}
+
+// ---- kernel: fused frame ----------------------------------------------------------------
+struct FrameArgs {
+    Camera cam;
+    uint32_t width, height, samples;
+    uint64_t seed;
+    uint64_t pixel_begin, pixel_count;
+    float *fb;       // [3][pixel_count]
+    uint8_t *fb_u8;  // [pixel_count][3] or null
+};
+
+// GROUP lanes share one sub-pixel: lane j of the group owns numpy's pairwise accumulator
+// r[j] (samples j, 8+j, 16+j, ...), so the summation order of np.mean is reproduced with
+// a 3-step butterfly and no shared memory.  GROUP == 1 serves samples < 8 (numpy sums
+// those sequentially).
+template <int MODE, int SC, int GROUP, bool RETIRE>
+__global__ __launch_bounds__(kBlock, (RETIRE && SC == kScene8 && GROUP == 8) ? 5 : (SC == kSceneGrid ? APT_GRID_WAVES : APT_FULL_WAVES)) void render_frame_kernel(const float *__restrict__ sph, FrameArgs fa,
+                                                              TraceArgs ta, LeafProg lp) {
+    constexpr bool NS8 = SC == kScene8;
+    __shared__ float4 tab[16];
+    __shared__ float4 tile[SC == kSceneTiles ? kTile : 1];
+    extern __shared__ float dyn_lds[];
+    float *stack_lds = dyn_lds;                                            // [kMaxStack][3][kStackSlots] when lp.nleaves > 1
+    float *queue_lds = dyn_lds + (lp.nleaves > 1 ? kMaxStack * 3 * kStackSlots : 0); // [waves][3][8*maxleaf] (refill)
+    // The camera frame (14 doubles) is only needed by ray-generate; parked in LDS it does not
+    // occupy 28 SGPRs across the bounce loop (they spilled to VGPR lanes otherwise).
+    __shared__ Camera cam;
+    if (threadIdx.x < sizeof(Camera) / sizeof(double)) (&cam.pos[0])[threadIdx.x] = (&fa.cam.pos[0])[threadIdx.x];
+    Scene8 sc;
+    if (NS8) load_scene8(sph, sc, tab);
+    else __syncthreads();
+
+    const uint32_t lane = threadIdx.x & 63;
+    const uint64_t L = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    const uint32_t j = (GROUP == 8) ? (uint32_t)(L & 7) : 0u;
+    const uint32_t sub = (uint32_t)(L / GROUP) & 3u;
+    const uint64_t pl = L / (4 * GROUP);
+    const bool valid = pl < fa.pixel_count;
+    const uint64_t q = fa.pixel_begin + (valid ? pl : 0);
+    const uint32_t pi = (uint32_t)(q / fa.height), pj = (uint32_t)(q % fa.height);
+    const uint32_t sy = sub >> 1, sx = sub & 1;
+    const uint64_t pbase = (q * 4 + sub) * fa.samples;
+    uint32_t traced = 0;
+
+    const Gain3 gain = load_gain(sph, ta);
+    struct Col { float r, g, b; };
+    auto sample = [&](uint32_t k) -> Col {
+        double u1, u2;
+        path_uniforms(fa.seed, pbase + k, u1, u2);
+        float rox, roy, roz, rdx, rdy, rdz;
+        camera_ray(cam, fa.width, fa.height, pi, pj, sy, sx, u1, u2, rox, roy, roz, rdx, rdy, rdz);
+        PathState s;
+        path_init(s, rox, roy, roz, rdx, rdy, rdz);
+        if (SC == kScene8) traced += trace_ns8<MODE, RETIRE>(sc, tab, s, valid, ta, pbase + k);
+        else if (SC == kSceneGrid) traced += trace_grid<MODE, RETIRE>(sph, ta.grid, s, valid, ta, pbase + k);
+        else traced += trace_dyn<MODE, RETIRE>(sph, tile, s, valid, ta, pbase + k);
+        return Col{s.rx * gain.r, s.ry * gain.g, s.rz * gain.b};
+    };
+    auto add = [](const Col &a, const Col &b) { return Col{a.r + b.r, a.g + b.g, a.b + b.b}; };
+
+    float res[3] = {0.0f, 0.0f, 0.0f};
+    uint32_t start = 0;
+    int sp = 0;
+    for (uint32_t leaf = 0; leaf < lp.nleaves; ++leaf) {
+        const uint32_t n = lp.len(leaf);
+        float acc[3];
+        if (GROUP == 1) { // n < 8: res = 0; res += a[i]
+            Col a = {0.0f, 0.0f, 0.0f};
+            for (uint32_t k = 0; k < n; ++k) a = add(a, sample(start + k));
+            acc[0] = a.r; acc[1] = a.g; acc[2] = a.b;
+        } else {          // 8 <= n <= 128: r[j] chains, tree, tail
+            const uint32_t nfull = n & ~7u;
+            if (RETIRE && NS8) {
+                // Active-ray compaction with a wave-level work queue.  The 8 sub-pixel groups of the
+                // wave have 8*nfull samples in this leaf; instead of binding sample k of group g to
+                // lane (g, k mod 8), any lane that runs out of work takes the next unissued sample:
+                // a ballot of the lanes with an empty one-ray slot, a prefix count (mbcnt) as the
+                // rank inside the batch, item = next + rank.  Finished colours are parked in a
+                // per-wave LDS array indexed by the sample, and lane (g, j) then adds its own chain
+                // j, 8+j, ... from there IN ORDER, so numpy's summation order is untouched and the
+                // frame stays bit-identical.  Ray-generate (float64, the expensive part) runs for
+                // the whole wave only when >= kRefillLanes lanes want a ray or nothing else is left.
+                float *colq = queue_lds + (size_t)(threadIdx.x >> 6) * 3u * 8u * lp.maxleaf; // [3][8*maxleaf]
+                const uint32_t total = 8u * nfull;        // items of this wave in this leaf (uniform)
+                const uint32_t qstride = 8u * lp.maxleaf;
+                uint32_t next = 0;                        // first unissued item (uniform)
+                uint32_t depth_left = 0, cur_item = 0, slot_item = 0;
+                uint64_t cur_key = 0, slot_key = 0;       // Russian-roulette keys of the running / waiting path
+                uint32_t n_bounce_exec = 0, n_gen_exec = 0; // wave-level executions (statistics only)
+                float sl_ox = 0.f, sl_oy = 0.f, sl_oz = 0.f, sl_dx = 0.f, sl_dy = 0.f, sl_dz = 1.f; // the one-ray slot
+                bool slot_full = false, slot_valid = false, cur_valid = false;
+                PathState s;
+                path_init(s, 0.f, 0.f, 0.f, 0.f, 0.f, 1.f);
+                for (;;) {
+                    const bool want = !slot_full;
+                    const unsigned long long wants = __ballot(want);
+                    const bool busy_any = __any(depth_left != 0 || slot_full);
+                    if (next < total && wants && ((uint32_t)__popcll(wants) >= ta.refill_lanes || !busy_any)) {
+                        ++n_gen_exec;
+                        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(wants >> 32),
+                                              __builtin_amdgcn_mbcnt_lo((uint32_t)wants, 0u));
+                        const uint32_t remaining = total - next;
+                        const bool take = want && rank < remaining;
+                        // group coordinates come from the first lane of the item's group; every lane
+                        // of the wave takes part in the shuffles (a masked-off source lane would
+                        // return garbage), lanes that do not take an item use item 0
+                        const uint32_t item = take ? next + rank : 0u;
+                        const uint32_t g = item / nfull, k = item - g * nfull;
+                        const int src = (int)(8u * g);
+                        const uint32_t gpi = __shfl(pi, src, 64), gpj = __shfl(pj, src, 64);
+                        const uint32_t gsub = __shfl(sub, src, 64);
+                        const uint32_t blo = __shfl((uint32_t)pbase, src, 64), bhi = __shfl((uint32_t)(pbase >> 32), src, 64);
+                        const bool gvalid = __shfl((int)valid, src, 64) != 0;
+                        if (take) {
+                            slot_valid = gvalid;
+                            double u1, u2;
+                            const uint64_t path = (((uint64_t)bhi << 32) | blo) + start + k;
+                            if (ta.rr_start) slot_key = rr_path_key(ta.seed, path);
+                            path_uniforms(fa.seed, path, u1, u2);
+                            camera_ray(cam, fa.width, fa.height, gpi, gpj, gsub >> 1, gsub & 1u, u1, u2, sl_ox, sl_oy, sl_oz, sl_dx,
+                                       sl_dy, sl_dz);
+                            slot_item = item;
+                            slot_full = true;
+                        }
+                        next += min((uint32_t)__popcll(wants), remaining);
+                    }
+                    if (depth_left == 0 && slot_full) { // start the waiting ray
+                        path_init(s, sl_ox, sl_oy, sl_oz, sl_dx, sl_dy, sl_dz);
+                        cur_item = slot_item;
+                        cur_key = slot_key;
+                        cur_valid = slot_valid;
+                        depth_left = ta.depth;
+                        slot_full = false;
+                        if (ta.depth == 0 || !cur_valid) { // depth 0, or a group past the image: colour = gain
+                            depth_left = 0;
+                            colq[cur_item] = gain.r; colq[qstride + cur_item] = gain.g; colq[2 * qstride + cur_item] = gain.b;
+                        }
+                    }
+                    const bool active = depth_left != 0;
+                    if (!__any(active)) {
+                        if (next >= total && !__any(slot_full)) break;
+                        continue;
+                    }
+                    ++n_bounce_exec;
+                    PathState nx;
+                    bool redo = bounce_ns8<MODE, true>(sc, tab, s, nx, ta);
+                    redo = redo && active;
+                    if (__builtin_expect(__any(redo), 0)) { // exact re-run, see trace_ns8
+                        asm volatile("" ::: "memory");
+                        (void)bounce_ns8<MODE, false>(sc, tab, s, nx, ta);
+                    }
+                    if (ta.rr_start && ta.depth - depth_left + 1 >= ta.rr_start) // 0-based bounce index = depth - depth_left
+                        russian_roulette(nx, cur_key, ta.depth - depth_left);
+                    // inactive lanes computed on stale state; whatever they hold is overwritten when
+                    // they start their next ray, so the update itself needs no mask
+                    s = nx;
+                    traced += active ? 1u : 0u;
+                    depth_left -= active ? 1u : 0u;
+                    if (active && (depth_left == 0 || path_finished(s))) {
+                        depth_left = 0;
+                        colq[cur_item] = s.rx * gain.r;
+                        colq[qstride + cur_item] = s.ry * gain.g;
+                        colq[2 * qstride + cur_item] = s.rz * gain.b;
+                    }
+                }
+                __syncthreads(); // colours of the whole leaf are in LDS (only wave-local data is read back)
+                {   // lane (g, j) adds samples j, 8+j, ... of its own group, in order: numpy's r[j] chain
+                    const uint32_t base = (lane >> 3) * nfull + j;
+#pragma unroll
+                    for (int ch = 0; ch < 3; ++ch) acc[ch] = colq[ch * qstride + base];
+                    for (uint32_t i8 = 8; i8 < nfull; i8 += 8) {
+#pragma unroll
+                        for (int ch = 0; ch < 3; ++ch) acc[ch] = acc[ch] + colq[ch * qstride + base + i8];
+                    }
+                }
+                __syncthreads(); // before the next leaf reuses the array
+                if (ta.traced && lane == 0) { // lane-slots spent: executions x 64
+                    atomicAdd(ta.traced + 1, 64ull * n_bounce_exec);
+                    atomicAdd(ta.traced + 2, 64ull * n_gen_exec);
+                }
+            } else {
+                Col a = sample(start + j);
+                for (uint32_t i8 = 8; i8 < nfull; i8 += 8) a = add(a, sample(start + i8 + j));
+                acc[0] = a.r; acc[1] = a.g; acc[2] = a.b;
+            }
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) { // ((r0+r1)+(r2+r3)) + ((r4+r5)+(r6+r7))
+                float v = acc[ch];
+                v = v + __shfl_xor(v, 1, 64);
+                v = v + __shfl_xor(v, 2, 64);
+                v = v + __shfl_xor(v, 4, 64);
+                acc[ch] = v;
+            }
+            const uint32_t nt = n - nfull;
+            if (nt) { // res += a[i] for the n % 8 trailing samples, in order
+                const Col c = sample(start + nfull + (j < nt ? j : 0));
+                for (uint32_t t = 0; t < nt; ++t) {
+                    const int src = (int)((lane & ~7u) + t);
+                    acc[0] = acc[0] + __shfl(c.r, src, 64);
+                    acc[1] = acc[1] + __shfl(c.g, src, 64);
+                    acc[2] = acc[2] + __shfl(c.b, src, 64);
+                }
+            }
+        }
+        start += n;
+        if (lp.nleaves == 1) {
+            res[0] = acc[0]; res[1] = acc[1]; res[2] = acc[2];
+        } else { // pairwise(left) + pairwise(right), innermost first
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) stack_lds[(sp * 3 + ch) * kStackSlots + (threadIdx.x >> 3)] = acc[ch];
+            ++sp;
+            for (uint32_t m = 0; m < lp.ncomb(leaf); ++m) {
+                --sp;
+#pragma unroll
+                for (int ch = 0; ch < 3; ++ch) {
+                    const float a = stack_lds[((sp - 1) * 3 + ch) * kStackSlots + (threadIdx.x >> 3)];
+                    const float b = stack_lds[(sp * 3 + ch) * kStackSlots + (threadIdx.x >> 3)];
+                    stack_lds[((sp - 1) * 3 + ch) * kStackSlots + (threadIdx.x >> 3)] = a + b;
+                }
+            }
+        }
+    }
+    if (lp.nleaves > 1) {
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) res[ch] = stack_lds[ch * kStackSlots + (threadIdx.x >> 3)];
+    }
+
+    // decode_color: data_visualization.py:36-57
+    const float fs = (float)fa.samples;
+    const int gbase = (int)(lane & ~(uint32_t)(4 * GROUP - 1));
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+        const float mean = res[ch] / fs;            // np.mean: float32 sum / count
+        double acc = 0.0;                           // :38 sum_color = zeros (float64)
+#pragma unroll
+        for (int sq = 0; sq < 4; ++sq) acc = acc + (double)__shfl(mean, gbase + sq * GROUP, 64); // :41-45
+        const double v = acc / 4;                   // :46
+        const double cl = v < 0 ? 0 : (v > 1 ? 1 : v); // :54
+        if (valid && (lane & (4 * GROUP - 1)) == 0) {
+            fa.fb[(uint64_t)ch * fa.pixel_count + pl] = (float)cl;
+            if (fa.fb_u8) fa.fb_u8[pl * 3 + ch] = (uint8_t)(cl * 255); // :55-57 truncation
+        }
+    }
+    count_traced(ta, valid ? traced : 0);
+}
+
+// ---- kernel: first-hit debug oracle (gen_data.py:134-188 test_scene) ---------------------------
+// out[3][N]: emission of the light when it is the first hit, the sphere's colour otherwise, 0 when
+// nothing is hit.  One lane per ray, spheres read straight from the [10][Ns] planes (L2-resident).
+__global__ __launch_bounds__(kBlock) void test_scene_kernel(const float *__restrict__ rays,
+                                                            const float *__restrict__ sph, float *__restrict__ out,
+                                                            uint64_t n_total, uint32_t ns, int32_t light, float eps) {
+    const uint64_t p = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (p >= n_total) return;
+    const float ox = rays[p], oy = rays[n_total + p], oz = rays[2 * n_total + p];
+    const float dx = rays[3 * n_total + p], dy = rays[4 * n_total + p], dz = rays[5 * n_total + p];
+    float mind = kMissT;
+    int id = -1;
+    for (uint32_t k = 0; k < ns; ++k)
+        test_scene_sphere(sph[ns + k], sph[2 * (size_t)ns + k], sph[3 * (size_t)ns + k], sph[k], ox, oy, oz, dx, dy, dz,
+                          eps, (int)k, mind, id);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float v = 0.0f;
+        if (id >= 0) v = (id == light) ? sph[(size_t)(4 + c) * ns + id] : sph[(size_t)(7 + c) * ns + id]; // :175-180
+        out[(uint64_t)c * n_total + p] = v;
+    }
+}
+
+// ---- kernel: device gen_rays (counter RNG) -----------------------------------------------
+__global__ __launch_bounds__(kBlock) void gen_rays_kernel(Camera cam, uint32_t width, uint32_t height,
+                                                          uint32_t samples, uint64_t seed, uint64_t n_total,
+                                                          uint64_t begin, uint64_t count, float *__restrict__ rays) {
+    const uint64_t local = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (local >= count) return;
+    const uint64_t p = begin + local;
+    uint32_t i, j, sy, sx;
+    path_coords(p, height, samples, i, j, sy, sx);
+    double u1, u2;
+    path_uniforms(seed, p, u1, u2);
+    float rox, roy, roz, rdx, rdy, rdz;
+    camera_ray(cam, width, height, i, j, sy, sx, u1, u2, rox, roy, roz, rdx, rdy, rdz);
+    rays[p] = rox; rays[n_total + p] = roy; rays[2 * n_total + p] = roz;
+    rays[3 * n_total + p] = rdx; rays[4 * n_total + p] = rdy; rays[5 * n_total + p] = rdz;
+}
+
+// ---- kernel: device gen_rays, bit-exact with the reference's MT19937 stream -------------------
+// np.random.rand() takes two MT19937 words per double and gen_rays two doubles per path, in path
+// order (gen_data.py:32-40), so output block b of the generator (624 words) is exactly paths
+// [156b, 156b+156).  One workgroup per checkpoint: load the raw state of block cb = i*stride into
+// LDS, emit that block, then `twist` forward block by block.  The twist is the textbook 3-phase
+// parallel form: x[i] depends on x[i], x[i+1] and x[i+397], so [0,227), [227,454), [454,624) can each
+// be updated at once (read, barrier, write, barrier).
+constexpr int kMtN = 624, kMtM = 397, kPathsPerBlock = 156;
+
+__device__ __forceinline__ uint32_t mt_temper(uint32_t y) {
+    y ^= y >> 11;
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= y >> 18;
+    return y;
+}
+
+__global__ __launch_bounds__(kBlock) void gen_rays_mt_kernel(const uint32_t *__restrict__ checkpoints, uint32_t stride,
+                                                             uint64_t num_blocks, Camera cam, uint32_t width,
+                                                             uint32_t height, uint32_t samples, uint64_t n_total,
+                                                             uint64_t begin, uint64_t end, float *__restrict__ rays) {
+    __shared__ uint32_t mt[kMtN];
+    const uint64_t cb = (uint64_t)blockIdx.x * stride;         // first output block of this workgroup
+    for (int i = threadIdx.x; i < kMtN; i += kBlock) mt[i] = checkpoints[(uint64_t)blockIdx.x * kMtN + i];
+    __syncthreads();
+    const uint64_t last = min(cb + stride, num_blocks);
+    for (uint64_t blk = cb; blk < last; ++blk) {
+        if (blk != cb) { // twist to the next block
+            const int t = threadIdx.x;
+            const int lo[3] = {0, 227, 454}, hi[3] = {227, 454, 624};
+#pragma unroll
+            for (int ph = 0; ph < 3; ++ph) {
+                const int i = lo[ph] + t;
+                uint32_t v = 0;
+                const bool on = i < hi[ph];
+                if (on) {
+                    const uint32_t y = (mt[i] & 0x80000000u) | (mt[(i + 1) % kMtN] & 0x7fffffffu);
+                    v = mt[(i + kMtM) % kMtN] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+                }
+                __syncthreads();
+                if (on) mt[i] = v;
+                __syncthreads();
+            }
+        }
+        const uint64_t p = blk * kPathsPerBlock + threadIdx.x;
+        if (threadIdx.x < kPathsPerBlock && p >= begin && p < end) {
+            const uint32_t a1 = mt_temper(mt[4 * threadIdx.x]) >> 5, b1 = mt_temper(mt[4 * threadIdx.x + 1]) >> 6;
+            const uint32_t a2 = mt_temper(mt[4 * threadIdx.x + 2]) >> 5, b2 = mt_temper(mt[4 * threadIdx.x + 3]) >> 6;
+            const double u1 = ((double)a1 * 67108864.0 + (double)b1) / 9007199254740992.0; // random_sample
+            const double u2 = ((double)a2 * 67108864.0 + (double)b2) / 9007199254740992.0;
+            uint32_t i, j, sy, sx;
+            path_coords(p, height, samples, i, j, sy, sx);
+            float rox, roy, roz, rdx, rdy, rdz;
+            camera_ray(cam, width, height, i, j, sy, sx, u1, u2, rox, roy, roz, rdx, rdy, rdz);
+            rays[p] = rox; rays[n_total + p] = roy; rays[2 * n_total + p] = roz;
+            rays[3 * n_total + p] = rdx; rays[4 * n_total + p] = rdy; rays[5 * n_total + p] = rdz;
+        }
+    }
+}
+
+// ---- kernel: device decode_color -----------------------------------------------------------
+__device__ float pairwise_leaf(const float *a, uint32_t n) { // numpy pairwise_sum, n <= 128
+    if (n < 8) {
+        float r = 0.0f;
+        for (uint32_t i = 0; i < n; ++i) r = r + a[i];
+        return r;
+    }
+    float r[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) r[k] = a[k];
+    uint32_t i;
+    for (i = 8; i < n - (n % 8); i += 8) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) r[k] = r[k] + a[i + k];
+    }
+    float res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < n; ++i) res = res + a[i];
+    return res;
+}
+
+// one thread per (pixel, channel, sub-pixel); 4 adjacent lanes combine in float64
+__global__ __launch_bounds__(kBlock) void decode_color_kernel(const float *__restrict__ colors, uint32_t samples,
+                                                              uint64_t npix, LeafProg lp, float *__restrict__ fb,
+                                                              uint8_t *__restrict__ fb_u8) {
+    const uint64_t L = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    const uint32_t sub = (uint32_t)(L & 3);
+    const uint64_t pc = L >> 2; // pixel * 3 + channel, channel-major: pc = ch * npix + q
+    const bool valid = pc < 3 * npix;
+    const uint64_t ch = valid ? pc / npix : 0, q = valid ? pc % npix : 0;
+    const uint64_t n_total = npix * 4 * samples;
+    const float *a = colors + ch * n_total + (q * 4 + sub) * samples;
+    float st[kMaxStack];
+    int sp = 0;
+    uint32_t start = 0;
+    for (uint32_t leaf = 0; leaf < lp.nleaves; ++leaf) {
+        st[sp++] = pairwise_leaf(a + start, lp.len(leaf));
+        start += lp.len(leaf);
+        for (uint32_t m = 0; m < lp.ncomb(leaf); ++m) { --sp; st[sp - 1] = st[sp - 1] + st[sp]; }
+    }
+    const float mean = st[0] / (float)samples;
+    const int gbase = (int)((threadIdx.x & 63) & ~3u);
+    double acc = 0.0;
+#pragma unroll
+    for (int sq = 0; sq < 4; ++sq) acc = acc + (double)__shfl(mean, gbase + sq, 64);
+    const double v = acc / 4;
+    const double cl = v < 0 ? 0 : (v > 1 ? 1 : v);
+    if (valid && sub == 0) {
+        fb[ch * npix + q] = (float)cl;
+        if (fb_u8) fb_u8[q * 3 + ch] = (uint8_t)(cl * 255);
+    }
+}
+
+// ---- kernel: exhaustive self-test of the fast correctly-rounded sqrt ------------------------
+// Every float bit pattern in [begin, begin+count): variant(x) must equal sqrtf(x) bit for bit
+// (any NaN == any NaN) unless the variant asks for the fallback (|x| < 2^-96), in which case the
+// hot loop would have used sqrtf() anyway.  Counts mismatches; remembers the first one.
+__global__ __launch_bounds__(kBlock) void selftest_sqrt_kernel(int variant, uint64_t begin, uint64_t count,
+                                                               unsigned long long *result) {
+#if defined(__HIP_DEVICE_COMPILE__) // the sqrt variants are device-only builtins
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    unsigned long long bad = 0, first = ~0ull;
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < count; i += stride) {
+        const uint32_t bits = (uint32_t)(begin + i);
+        const float x = __uint_as_float(bits);
+        float amin = 1.0f;
+        const float got = variant == 0 ? sqrt_rn_core(x, amin) : variant == 1 ? sqrt_rn_markstein(x, amin)
+                        : variant == 2 ? sqrt_rn_rsq1(x, amin) : sqrt_rn_rsq2(x, amin);
+        const float want = sqrtf(x);
+        const bool fallback = amin < 0x1p-96f;
+        const bool same = (__float_as_uint(got) == __float_as_uint(want)) || (got != got && want != want);
+        if (!same && !fallback) { ++bad; if (first == ~0ull) first = bits; }
+    }
+    if (bad) {
+        atomicAdd(&result[0], bad);
+        atomicMin(&result[1], first);
+    }
+#endif
+}
+
+// ---- kernel: self-test of the shared-reciprocal divide --------------------------------------
+// Operand set i of [begin, begin+count): three numerators built from a counter hash, the divisor
+// formed from them exactly as the shading step does (sqrt of the sum of squares); a quarter of the
+// sets use special mantissas (all ones, 1.0, powers of two, one-bit neighbours), exponents at the
+// edges of the accepted range and signed zeros.  Every set the validity flags accept must give the
+// three quotients of the plain `/` bit for bit.
+__global__ __launch_bounds__(kBlock) void selftest_div3_kernel(uint64_t begin, uint64_t count,
+                                                               unsigned long long *result) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    unsigned long long bad = 0, first = ~0ull, accepted = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < count; i += stride) {
+        uint64_t h = splitmix64(begin + i);
+        float v[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            h = splitmix64(h);
+            // exponents over the whole accepted range and a little beyond it on both sides
+            uint32_t man = (uint32_t)h & 0x7fffffu, ex = 127u - 100u + (uint32_t)((h >> 23) % 134u), sg = (uint32_t)(h >> 63);
+            if (((begin + i) & 3u) == 0u) {
+                const uint32_t pick = (uint32_t)(h >> 40) & 7u;
+                man = pick == 0 ? 0x7fffffu : pick == 1 ? 0u : pick == 2 ? 1u : pick == 3 ? 0x7ffffeu
+                    : pick == 4 ? 0x400000u : pick == 5 ? 0x3fffffu : pick == 6 ? 0x400001u : man;
+                if (((h >> 44) & 3u) == 0u) ex = ((h >> 46) & 1u) ? 127u - 96u : 127u + 29u;
+            }
+            v[k] = __uint_as_float((sg << 31) | (ex << 23) | man);
+        }
+        if (((begin + i) & 63u) == 1u) v[((begin + i) >> 6) % 3u] = ((begin + i) & 64u) ? 0.0f : -0.0f; // zero numerators
+        // the divisor exactly as the shading step forms it (K-mode order; O-mode differs by one rounding)
+        float len2 = 0.0f + v[0] * v[0];
+        len2 = len2 + v[1] * v[1];
+        len2 = len2 + v[2] * v[2];
+        const float d = sqrtf(len2);
+        float ux, uy, uz, amin = 1.0f;
+        uint32_t hiflag = 0;
+        div3_shared(v[0], v[1], v[2], d, len2, ux, uy, uz, amin, hiflag);
+        if (amin < 0x1p-96f || (int32_t)hiflag < 0) continue; // the kernel redoes these with '/'
+        ++accepted;
+        const float wx = v[0] / d, wy = v[1] / d, wz = v[2] / d;
+        if (__float_as_uint(ux) != __float_as_uint(wx) || __float_as_uint(uy) != __float_as_uint(wy) ||
+            __float_as_uint(uz) != __float_as_uint(wz)) { ++bad; if (first == ~0ull) first = begin + i; }
+    }
+    if (bad) { atomicAdd(&result[0], bad); atomicMin(&result[1], first); }
+    atomicAdd(&result[2], accepted);
+#endif
+}
+
+
+} // namespace
