@@ -167,3 +167,20 @@ def test_scene(params: RenderParams, rays, spheres, stream=None):
                                _dev_f32(spheres, "spheres", sphere_floats(params.num_spheres)),
                                _dev_f32(out, "out")), "apt_test_scene")
     return out.view(3, -1)
+
+
+def render_reference_frame(w, h, s, depth=5, seed=0, spheres=None, mode=None, flags=0, stream=None):
+    """The reference's whole pipeline on the device, bit-exact with running scripts/gen_data.py
+    (np.random.seed(seed); gen_rays; gen_spheres; test_soa) and scripts/data_visualization.py:
+    MT19937 gen_rays -> render (O-mode by default = the NumPy oracle's arithmetic) -> decode_color.
+    -> (fb float32 [3][W*H], fb_u8 uint8 [W*H][3], colors [3][N]); not synchronised."""
+    from . import gen_data
+    from ._lib import APT_MODE_ORACLE, make_params
+    require_gpu()
+    if spheres is None:
+        spheres = torch.from_numpy(gen_data.gen_spheres()).cuda()
+    p = make_params(w, h, s, depth=depth, mode=APT_MODE_ORACLE if mode is None else mode, flags=flags)
+    rays = gen_data.gen_rays_device(w, h, s, seed=seed, stream=stream)
+    colors = render_paths(p, rays.reshape(-1), spheres, stream=stream)
+    fb, u8 = decode_color_device(p, colors, stream=stream)
+    return fb, u8, colors
