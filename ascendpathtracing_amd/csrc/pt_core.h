@@ -145,6 +145,9 @@ __device__ __forceinline__ void div3_shared(float nx, float ny, float nz, float 
     // 2^-96; +-0 is flagged too, which only costs an exact re-run); the second is the sign bit of
     // bits(2^60) - bits(len2) (len2 >= 0 or NaN), OR-ed into `hiflag` with 2-cycle integer ops.
     // len2 itself must not have underflowed (d would be 0 or unrelated to the numerators).
+    // The seed must be v_rcp_f32(d) itself: seeding from the sqrt's v_rsq_f32(len2) (error ~1.5 ulp of
+    // 1/d) passes 2^30 random operand sets but fails 0.6 % of the self-test's structured ones (divisor
+    // mantissa all ones, where 1/d sits 2^-48 from a rounding midpoint) -- measured, rejected.
     amin = fminf(fminf(amin, fabsf(nx)), fminf(fabsf(ny), fabsf(nz)));
     amin = fminf(amin, len2);
     hiflag |= 0x5d800000u - __float_as_uint(len2);
@@ -284,7 +287,7 @@ APT_HD void shade_and_reflect(PathState &s, float tmin, float cx, float cy, floa
     }
     const float len2 = L; (void)len2;
 #if defined(__HIP_DEVICE_COMPILE__)
-    if (FAST) L = sqrt_rn_core(L, *amin);
+    if (FAST) L = sqrt_rn_rsq1(L, *amin);   // exact for every float but +inf, which div3_shared's hiflag sends to the re-run
     else
 #endif
         L = sqrtf(L);                                           // :658
