@@ -4,7 +4,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librender_mi355x.so")
+# APT_LIB_PATH: another build of the same library (A/B timing of kernel variants); still no fallback
+LIB_PATH = os.environ.get("APT_LIB_PATH") or os.path.join(_HERE, "librender_mi355x.so")
 
 APT_OK = 0
 APT_MODE_KERNEL, APT_MODE_ORACLE = 0, 1

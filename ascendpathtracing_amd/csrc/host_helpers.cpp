@@ -10,6 +10,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <vector>
 
 #include "../../include/render_mi355x.h"
@@ -164,7 +165,7 @@ int apt_gen_scene_host(uint32_t num_spheres, uint64_t seed, float *spheres, size
 // they go to an always-tested list; the others are binned by their bounding boxes, inflated by `margin`
 // so that any ray the fp32 intersection formula can possibly accept passes through the interior of a
 // cell that lists the sphere (the formula's absolute error on disc is ~1e-3 at these coordinates; the
-// margin is 0.05 + 1e-4 * coordinate scale).  Cells are sized for ~2 spheres each.
+// margin is 0.05 + 1e-4 * coordinate scale).  Cells are sized for ~1 sphere centre each (APT_GRID_SPHERES_PER_CELL overrides: tuning knob).
 int apt_build_grid_host(const float *sph, uint32_t ns, void *grid, size_t *out_bytes) {
     if (!sph || ns == 0 || !out_bytes) return APT_ERR_ARG;
     const float *r2 = sph, *cx = sph + ns, *cy = sph + 2 * (size_t)ns, *cz = sph + 3 * (size_t)ns;
@@ -192,7 +193,9 @@ int apt_build_grid_host(const float *sph, uint32_t ns, void *grid, size_t *out_b
     h.margin = 0.05f + 1e-4f * scale;
     for (int a = 0; a < 3; ++a) { lo[a] -= 2 * h.margin; hi[a] += 2 * h.margin; }
     const double vol = (double)(hi[0] - lo[0]) * (hi[1] - lo[1]) * (hi[2] - lo[2]);
-    const double target = std::max<size_t>(1, small.size() / 2);                   // ~2 spheres per cell
+    double per_cell = 1.0; // sphere centres per cell (boxes overlap ~4 cells each); measured 74.4 / 70.7 / 70.3 / 70.8 / 72.2 ms at 2 / 1 / 0.7 / 0.5 / 0.35
+    if (const char *e = getenv("APT_GRID_SPHERES_PER_CELL")) { const double v = atof(e); if (v > 0.01 && v < 1e6) per_cell = v; }
+    const double target = std::max(1.0, (double)small.size() / per_cell);
     const double edge = std::cbrt(std::max(vol, 1e-30) / target);
     for (int a = 0; a < 3; ++a) {
         const double n = std::ceil((hi[a] - lo[a]) / std::max(edge, 1e-30));
