@@ -92,6 +92,12 @@ KERNEL(k_sgpr_add, "v_add_f32 %0, %14, %2\nv_add_f32 %3, %4, %5\n")
 KERNEL(k_pk_pk_add_add, "v_pk_add_f32 %8, %9, %10\nv_pk_mul_f32 %11, %9, %10\nv_add_f32 %0, %1, %2\nv_mul_f32 %3, %4, %5\n")
 KERNEL(k_rsq_indep, "v_rsq_f32 %0, %1\nv_add_f32 %2, %3, %4\nv_add_f32 %5, %3, %4\nv_add_f32 %6, %3, %4\n")
 KERNEL(k_rsq_cmp, "v_rsq_f32 %0, %1\nv_cmp_lt_f32 vcc, %3, %4\n")
+#define F8(x) x x x x x x x x
+KERNEL(k_cnd8_add8, F8("v_cndmask_b32 %0, %1, %2, vcc\n") F8("v_add_f32 %3, %4, %5\n"))
+KERNEL(k_min8_add8, F8("v_min3_u32 %12, %13, %12, %13\n") F8("v_add_f32 %3, %4, %5\n"))
+KERNEL(k_cnd2_add2, "v_cndmask_b32 %0, %1, %2, vcc\nv_cndmask_b32 %6, %1, %2, vcc\nv_add_f32 %3, %4, %5\nv_add_f32 %7, %4, %5\n")
+KERNEL(k_pk_cnd_add, "v_pk_add_f32 %8, %9, %10\nv_cndmask_b32 %0, %1, %2, vcc\nv_add_f32 %3, %4, %5\n")
+KERNEL(k_cnd_mul_dep, "v_cndmask_b32 %0, %1, %2, vcc\nv_mul_f32 %3, %0, %5\n")
 KERNEL(k_readlane_like_dpp, "v_mov_b32_dpp %0, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n")
 
 typedef void (*kfn)(float *, int, float, float);
@@ -118,6 +124,7 @@ int main() {
         {"v_cvt_f64_u32", k_cvt_f64_u32, 1}, {"v_cmp_lt_f64", k_cmp_f64, 1}, {"v_pk_add_f32 (sgpr pair)", k_pk_add_sgpr, 1}, {"v_pk_add_f32 (sgpr pair, neg)", k_pk_add_sgpr_neg, 1},
         {"v_pk_mul_f32 op_sel_hi", k_pk_mul_opsel, 1}, {"v_min_u32", k_min_u32, 1}, {"v_min3_u32", k_min3_u32, 1}, {"v_subrev_u32", k_subrev_u32, 1},
         {"v_cmp_le_u32 (vcc)", k_cmp_u32, 1}, {"v_pk_mov_b32", k_pk_mov, 1}, {"v_fmac_f32", k_fmac, 1}, {"v_mul_f32 (sgpr src)", k_mul_f32_sgpr, 1},
+        {"8 v_cndmask then 8 v_add (group of 16)", k_cnd8_add8, 16}, {"8 v_min3_u32 then 8 v_add (group of 16)", k_min8_add8, 16}, {"2 v_cndmask then 2 v_add (group of 4)", k_cnd2_add2, 4}, {"v_pk_add + v_cndmask + v_add (group of 3)", k_pk_cnd_add, 3}, {"v_cndmask + dependent v_mul (group of 2)", k_cnd_mul_dep, 2},
         {"4 independent v_add_f32", k_add_4indep, 4}, {"v_pk_add + v_pk_mul (different dst)", k_pk_4indep, 2}, {"s_nop 0", k_nop, 1}};
     const int iters = 2000, blocks = 256 * 8; // 8 blocks of 4 waves per CU -> 8 waves per SIMD
     hipEvent_t a, b;
