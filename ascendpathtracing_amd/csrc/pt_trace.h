@@ -269,15 +269,50 @@ __device__ __forceinline__ uint32_t trace_grid(const float *__restrict__ sph, co
         float tmin = kMissT;
         int idx = (MODE == kModeOracle) ? -1 : 0;
         auto test_geom = [&](const float4 g, uint32_t k) {
-            ++n_tests;
             const HitPre hp = intersect_pre(g.x, g.y, g.z, g.w, s.ox, s.oy, s.oz, s.dx, s.dy, s.dz);
             if (hp.disc >= 0.0f) {
                 const float t = intersect_post(hp, ta.eps);
                 if (t < tmin || (t == tmin && (int)k < idx)) { tmin = t; idx = (int)k; }
             }
         };
-        auto test = [&](uint32_t k) { test_geom(geom[k], k); };
-        for (uint32_t i = 0; i < h.nlarge; ++i) test(large[i]); // wave-uniform: scalar loads
+        auto test = [&](uint32_t k) { ++n_tests; test_geom(geom[k], k); };
+        // A candidate of the walk is identified by its position in the item list; the sphere index (one more
+        // dependent load per candidate) is only fetched when it matters: on an exact tie of t -- mostly the same
+        // sphere met again in the next cell -- and once at the end for the winner.
+        uint32_t pos = ~0u; // item position of the running minimum, ~0u while `idx` itself is authoritative
+        auto test_item = [&](const float4 g, uint32_t i) {
+            const HitPre hp = intersect_pre(g.x, g.y, g.z, g.w, s.ox, s.oy, s.oz, s.dx, s.dy, s.dz);
+            if (hp.disc >= 0.0f) {
+                const float t = intersect_post(hp, ta.eps);
+                if (t < tmin) { tmin = t; pos = i; }
+                else if (t == tmin) {
+                    const int cur = (pos != ~0u) ? (int)items[pos] : idx;
+                    if ((int)items[i] < cur) pos = i;
+                }
+            }
+        };
+        // The large spheres are tested by every lane of the wave and (walls) hit by every ray, so the `disc >= 0`
+        // skip never fires for them: the exact single-rsq sqrt (pt_core.h) instead of sqrtf()'s full expansion.  A
+        // negative discriminant gives NaN roots and select_root's kMissT like the skipped form; +inf gives NaN
+        // instead of +inf, and neither can beat tmin <= kMissT.
+        auto test_large = [&](const float4 g, uint32_t k) {
+            ++n_tests;
+            const HitPre hp = intersect_pre(g.x, g.y, g.z, g.w, s.ox, s.oy, s.oz, s.dx, s.dy, s.dz);
+            float q;
+#if defined(__HIP_DEVICE_COMPILE__) // the sqrt variants are device-only builtins
+            float am = 1.0f;
+            q = sqrt_rn_rsq1(hp.disc, am);
+            if (__builtin_expect(__any(am < 0x1p-96f), 0)) { // |disc| below the fast sequence's range
+                asm volatile("" ::: "memory");
+                q = sqrtf(hp.disc);
+            }
+#else
+            q = sqrtf(hp.disc);
+#endif
+            const float t = select_root(hp.b - q, hp.b + q, ta.eps);
+            if (t < tmin || (t == tmin && (int)k < idx)) { tmin = t; idx = (int)k; }
+        };
+        for (uint32_t i = 0; i < h.nlarge; ++i) { const uint32_t k = large[i]; test_large(geom[k], k); } // wave-uniform: scalar loads
         const float dd = s.dx * s.dx + s.dy * s.dy + s.dz * s.dz;
         const bool unit = fabsf(dd - 1.0f) <= 1e-3f; // false for NaN/inf
         if (!fin && !unit) {
@@ -286,44 +321,55 @@ __device__ __forceinline__ uint32_t trace_grid(const float *__restrict__ sph, co
             // slab test against the grid box; all DDA state in scalars (no indexed arrays -> no scratch)
             float tn = 0.0f, tf = 3.0e38f;
             bool inbox = true;
-            auto slab = [&](float o, float dv, float lo, float hi) {
+            // One v_rcp_f32 per axis serves the slab test and the DDA increments (1 ulp is irrelevant here: the
+            // walk's exit test carries 1e-3 relative slack plus the binning margin, and a sphere near a cell corner is
+            // listed in every cell its inflated box touches, whichever of two near-simultaneous crossings comes first).
+            auto recip = [&](float dv) {
+#if defined(__HIP_DEVICE_COMPILE__)
+                return __builtin_amdgcn_rcpf(dv);
+#else
+                return 1.0f / dv;
+#endif
+            };
+            const float ix = recip(s.dx), iy = recip(s.dy), iz = recip(s.dz);
+            auto slab = [&](float o, float dv, float inv, float lo, float hi) {
                 if (fabsf(dv) > 1e-20f) {
-                    const float inv = 1.0f / dv, t1 = (lo - o) * inv, t2 = (hi - o) * inv;
+                    const float t1 = (lo - o) * inv, t2 = (hi - o) * inv;
                     tn = fmaxf(tn, fminf(t1, t2));
                     tf = fminf(tf, fmaxf(t1, t2));
                 } else if (!(o >= lo && o <= hi)) inbox = false;
             };
-            slab(s.ox, s.dx, h.gmin[0], h.gmax[0]);
-            slab(s.oy, s.dy, h.gmin[1], h.gmax[1]);
-            slab(s.oz, s.dz, h.gmin[2], h.gmax[2]);
+            slab(s.ox, s.dx, ix, h.gmin[0], h.gmax[0]);
+            slab(s.oy, s.dy, iy, h.gmin[1], h.gmax[1]);
+            slab(s.oz, s.dz, iz, h.gmin[2], h.gmax[2]);
             if (inbox && tn <= tf) {
-                auto axis = [&](float o, float dv, float lo, float cellw, float invw, int na, int &c, int &step, float &tmax,
-                                float &tdel) {
+                auto axis = [&](float o, float dv, float inv, float lo, float cellw, float invw, int na, int &c, int &step,
+                                float &tmax, float &tdel) {
                     int ci = (int)floorf((o + dv * tn - lo) * invw);
                     ci = ci < 0 ? 0 : (ci >= na ? na - 1 : ci);
                     c = ci;
-                    if (dv > 1e-20f) { step = 1; tmax = (lo + (float)(ci + 1) * cellw - o) / dv; tdel = cellw / dv; }
-                    else if (dv < -1e-20f) { step = -1; tmax = (lo + (float)ci * cellw - o) / dv; tdel = -cellw / dv; }
+                    if (dv > 1e-20f) { step = 1; tmax = (lo + (float)(ci + 1) * cellw - o) * inv; tdel = cellw * inv; }
+                    else if (dv < -1e-20f) { step = -1; tmax = (lo + (float)ci * cellw - o) * inv; tdel = -cellw * inv; }
                     else { step = 0; tmax = 3.0e38f; tdel = 3.0e38f; }
                 };
                 int c0, c1, c2, st0, st1, st2;
                 float tm0, tm1, tm2, td0, td1, td2;
-                axis(s.ox, s.dx, h.gmin[0], h.cell[0], h.inv_cell[0], n0, c0, st0, tm0, td0);
-                axis(s.oy, s.dy, h.gmin[1], h.cell[1], h.inv_cell[1], n1, c1, st1, tm1, td1);
-                axis(s.oz, s.dz, h.gmin[2], h.cell[2], h.inv_cell[2], n2, c2, st2, tm2, td2);
+                axis(s.ox, s.dx, ix, h.gmin[0], h.cell[0], h.inv_cell[0], n0, c0, st0, tm0, td0);
+                axis(s.oy, s.dy, iy, h.gmin[1], h.cell[1], h.inv_cell[1], n1, c1, st1, tm1, td1);
+                axis(s.oz, s.dz, iz, h.gmin[2], h.cell[2], h.inv_cell[2], n2, c2, st2, tm2, td2);
                 const int max_steps = n0 + n1 + n2 + 3;
                 for (int it = 0; it < max_steps; ++it) {
                     const uint32_t cell = (uint32_t)((c2 * n1 + c1) * n0 + c0);
                     const uint32_t b = cells[cell], e = cells[cell + 1];
                     ++n_cells;
+                    n_tests += e - b;
                     uint32_t i = b;
-                    for (; i + 2 <= e; i += 2) { // two candidates per step: four independent loads in flight
+                    for (; i + 2 <= e; i += 2) { // two candidates per step: their loads are in flight together
                         const float4 ga = item_geom[i], gb = item_geom[i + 1];
-                        const uint32_t ka = items[i], kb = items[i + 1];
-                        test_geom(ga, ka);
-                        test_geom(gb, kb);
+                        test_item(ga, i);
+                        test_item(gb, i + 1);
                     }
-                    if (i < e) test_geom(item_geom[i], items[i]);
+                    if (i < e) test_item(item_geom[i], i);
                     const float te = fminf(tm0, fminf(tm1, tm2));                      // parameter at which the ray leaves this cell
                     if (tmin < te - (1e-3f * fabsf(te) + h.margin)) break;             // nothing nearer can lie ahead
                     if (tm0 <= tm1 && tm0 <= tm2) { c0 += st0; tm0 += td0; if ((unsigned)c0 >= (unsigned)n0) break; }
@@ -332,10 +378,25 @@ __device__ __forceinline__ uint32_t trace_grid(const float *__restrict__ sph, co
                 }
             }
         }
-        if (!fin) { // per-lane code anyway: shade in place (no second copy of the path state in registers)
+        if (!fin) {
+            if (pos != ~0u) idx = (int)items[pos];
             const uint32_t g = (idx < 0) ? ns - 1 : (uint32_t)idx;
             const float4 gc = geom[g];
+#if defined(__HIP_DEVICE_COMPILE__)
+            {   // exact fast sqrt / shared-reciprocal divide (pt_core.h); out-of-range operands redo the step with sqrtf() and '/'
+                PathState n = s;
+                float amin = 1.0f;
+                shade_and_reflect<MODE, true>(n, tmin, gc.x, gc.y, gc.z, colx[g], coly[g], colz[g], idx == ta.light, &amin);
+                if (__builtin_expect(__any(amin < 0x1p-96f), 0)) {
+                    asm volatile("" ::: "memory");
+                    n = s;
+                    shade_and_reflect<MODE>(n, tmin, gc.x, gc.y, gc.z, colx[g], coly[g], colz[g], idx == ta.light);
+                }
+                s = n;
+            }
+#else
             shade_and_reflect<MODE>(s, tmin, gc.x, gc.y, gc.z, colx[g], coly[g], colz[g], idx == ta.light);
+#endif
             if (ta.rr_start && d + 1 >= ta.rr_start) russian_roulette(s, rr_key, d);
             ++traced;
         }
