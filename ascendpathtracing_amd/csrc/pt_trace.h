@@ -358,11 +358,26 @@ __device__ __forceinline__ uint32_t trace_grid(const float *__restrict__ sph, co
                 axis(s.oy, s.dy, iy, h.gmin[1], h.cell[1], h.inv_cell[1], n1, c1, st1, tm1, td1);
                 axis(s.oz, s.dz, iz, h.gmin[2], h.cell[2], h.inv_cell[2], n2, c2, st2, tm2, td2);
                 const int max_steps = n0 + n1 + n2 + 3;
+                uint32_t cell = (uint32_t)((c2 * n1 + c1) * n0 + c0);
+                uint32_t b = cells[cell], e = cells[cell + 1];
                 for (int it = 0; it < max_steps; ++it) {
-                    const uint32_t cell = (uint32_t)((c2 * n1 + c1) * n0 + c0);
-                    const uint32_t b = cells[cell], e = cells[cell + 1];
                     ++n_cells;
                     n_tests += e - b;
+                    // Which cell comes next depends on the crossing parameters only, not on what the candidates of
+                    // this cell turn out to be: fetch its item range now, so that the dependent load is in flight
+                    // while they are tested (the fetch is wasted when the walk ends here).
+                    const float te = fminf(tm0, fminf(tm1, tm2)); // parameter at which the ray leaves this cell
+                    const bool s0 = tm0 <= tm1 && tm0 <= tm2, s1 = !s0 && tm1 <= tm2, s2 = !s0 && !s1;
+                    if (s0) { c0 += st0; tm0 += td0; }
+                    if (s1) { c1 += st1; tm1 += td1; }
+                    if (s2) { c2 += st2; tm2 += td2; }
+                    const bool inside = (unsigned)c0 < (unsigned)n0 && (unsigned)c1 < (unsigned)n1 && (unsigned)c2 < (unsigned)n2;
+                    uint32_t nb = 0, ne = 0;
+                    if (inside) {
+                        cell = (uint32_t)((c2 * n1 + c1) * n0 + c0);
+                        nb = cells[cell];
+                        ne = cells[cell + 1];
+                    }
                     uint32_t i = b;
                     for (; i + 2 <= e; i += 2) { // two candidates per step: their loads are in flight together
                         const float4 ga = item_geom[i], gb = item_geom[i + 1];
@@ -370,11 +385,10 @@ __device__ __forceinline__ uint32_t trace_grid(const float *__restrict__ sph, co
                         test_item(gb, i + 1);
                     }
                     if (i < e) test_item(item_geom[i], i);
-                    const float te = fminf(tm0, fminf(tm1, tm2));                      // parameter at which the ray leaves this cell
-                    if (tmin < te - (1e-3f * fabsf(te) + h.margin)) break;             // nothing nearer can lie ahead
-                    if (tm0 <= tm1 && tm0 <= tm2) { c0 += st0; tm0 += td0; if ((unsigned)c0 >= (unsigned)n0) break; }
-                    else if (tm1 <= tm2) { c1 += st1; tm1 += td1; if ((unsigned)c1 >= (unsigned)n1) break; }
-                    else { c2 += st2; tm2 += td2; if ((unsigned)c2 >= (unsigned)n2) break; }
+                    if (tmin < te - (1e-3f * fabsf(te) + h.margin)) break; // nothing nearer can lie ahead
+                    if (!inside) break;
+                    b = nb;
+                    e = ne;
                 }
             }
         }
