@@ -67,6 +67,11 @@ for d, flags, name in ((8, 0, "C2 D8"), (8, apt.APT_FLAG_RETIRE, "C2 D8 retire")
     traced = tc.value // 2
     ms = timeit(lambda: render.render_frame(p, sph8), args.reps)
     report(f"{name} 1080p 256spp", ms, p.num_paths * d, 8, {"segments_traced": traced})
+# C3 (4096x4096, 1024 spp, D8, 8 GPUs): the band one of the 8 ranks renders (2 097 152 pixels, 17.2 G segments)
+p3 = apt.make_params(4096, 4096, 256, depth=8)
+npix3 = 4096 * 4096 // 8
+ms = timeit(lambda: render.render_frame(p3, sph8, 3 * npix3, npix3), 2)
+report("C3 4096x4096 1024spp D8, one rank's band of 8", ms, npix3 * 4 * 256 * 8, 8)
 # C2 through the reference's own pipeline, entirely on the device and bit-exact with it: MT19937 gen_rays ->
 # render_do_ex on a [6][N] ray buffer (12.7 GB) -> colours [3][N] (6.4 GB) -> decode_color.  O-mode = NumPy oracle.
 import time
