@@ -4,6 +4,7 @@ reference's own pipeline, GPU vs CPU restatement, every one of the 530,841,600 p
   gen_rays (MT19937, seed 0)  : device (checkpointed stream) vs the library's sequential host generator
   render (O-mode = NumPy oracle arithmetic, and K-mode)       : device vs oracle.render_paths (all host threads)
   decode_color                                               : device vs oracle.decode_color
+  fused frame kernel (the benchmarked one, counter-RNG rays)  : device vs oracle.render_frame, every pixel
 Checker code (oracle) is used here as the checker only.  ~70 s on 128 host threads, ~40 GB of host memory.
 Run directly (python tests/full_size_c2_parity.py) or through pytest with APT_FULL_PARITY=1
 (tests/test_gpu_parity.py::test_full_size_c2_parity); the round-1 log is profiles/r01_c2_full_parity.log."""
@@ -51,5 +52,17 @@ for mode, omode, name in ((apt.APT_MODE_ORACLE, oracle.MODE_O, "O"), (apt.APT_MO
         rms = float(torch.sqrt(((fb_f - fb_d) ** 2).mean()))
         log(f"RMS between this frame and the fused counter-RNG frame (different random jitter): {rms:.4f}")
     del col_d, col_h
+# the headline kernel itself: the fused frame (counter-RNG rays generated on the device, 4*S samples accumulated
+# on the device) against the CPU restatement's frame, every pixel, with and without result-preserving retirement
+del rays_d, rays_h
+torch.cuda.empty_cache()
+pk = apt.make_params(W, H, S, depth=D, mode=apt.APT_MODE_KERNEL, seed=0)
+fb_w, u8_w, _, traced = oracle.render_frame(oracle.make_params(W, H, S, depth=D, mode=oracle.MODE_K, seed=0), sph_h, threads=threads)
+log(f"oracle frame done ({traced} segments)")
+for flags, name in ((0, "frame_K"), (apt.APT_FLAG_RETIRE, "frame_K_retire")):
+    fb_g, u8_g = render.render_frame(pk.copy(flags=flags), sph); torch.cuda.synchronize()
+    ok = np.array_equal(fb_g.cpu().numpy().view(np.uint32), fb_w.view(np.uint32)) and np.array_equal(u8_g.cpu().numpy(), u8_w)
+    log(f"fused frame ({name}) bitwise equal to the CPU restatement, all {W * H} pixels: {ok}  sha256(u8)={hashlib.sha256(u8_w.tobytes()).hexdigest()[:16]}")
+    results[name] = ok
 log("RESULT " + ("PASS" if all(results.values()) else "FAIL") + " " + str(results))
 sys.exit(0 if all(results.values()) else 1)
