@@ -53,7 +53,18 @@ def cpu_baseline(budget_s=12.0):
         seg += traced
         done += cnt
     dt = time.perf_counter() - t0
-    return {"value": round(seg / dt / 1e6, 3), "unit": "Mray/s", "cores": threads, "kind": "port",
+
+    def short_run(nthreads, budget):   # also 1 thread and 8 threads (the reference's 8-block split)
+        t1, s1, k = time.perf_counter(), 0, 0
+        while time.perf_counter() - t1 < budget:
+            _, _, _, tr = oracle.render_frame(p, sph, pixel_begin=(k * 2654435761) % (npix - 256), pixel_count=256,
+                                              threads=nthreads)
+            s1 += tr
+            k += 1
+        return round(s1 / (time.perf_counter() - t1) / 1e6, 3)
+
+    by_threads = {"1": short_run(1, 2.0), "8": short_run(min(8, threads), 2.0)}
+    return {"value": round(seg / dt / 1e6, 3), "unit": "Mray/s", "cores": threads, "kind": "port", "by_threads": by_threads,
             "sample": f"{done} pixels of the {W}x{H} frame x {4 * S} spp x {D} bounces = {seg} segments in {dt:.1f} s "
                       f"(K-mode C restatement, gcc -O2 -ffp-contract=off, OpenMP)"}
 
