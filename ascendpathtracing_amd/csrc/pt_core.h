@@ -486,9 +486,8 @@ APT_HD Ray camera_ray(const Camera &c, uint32_t w, uint32_t h, uint32_t i, uint3
     return r;
 }
 
-// Counter-based generator for on-device ray generation: splitmix64 of (seed, path index)
-// seeds one xorshift64* stream; two 53-bit uniforms per path.  Integer-only, so host and
-// device agree bit for bit.
+// Counter-based generator for on-device ray generation (path_uniforms below); xorshift64* serves the
+// build-defined scene generator.  Integer-only, so host and device agree bit for bit.
 APT_HD uint64_t splitmix64(uint64_t x) {
     x += 0x9E3779B97F4A7C15ull;
     x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
@@ -501,11 +500,13 @@ APT_HD uint64_t xorshift64s(uint64_t &s) {
     s = x;
     return x * 0x2545F4914F6CDD1Dull;
 }
+// The two uniforms of path p are outputs 2p+1 and 2p+2 of ONE SplitMix64 generator (state += phi; output =
+// mix(state)) whose state starts at splitmix64(seed): every path reads its own two consecutive outputs of the
+// same well-tested stream by random access, state(p) = splitmix64(seed) + 2p*phi.  53 high bits each.
 APT_HD void path_uniforms(uint64_t seed, uint64_t path, double &u1, double &u2) {
-    uint64_t s = splitmix64(seed ^ splitmix64(path));
-    if (s == 0) s = 0x9E3779B97F4A7C15ull;
-    u1 = (double)(xorshift64s(s) >> 11) * (1.0 / 9007199254740992.0);
-    u2 = (double)(xorshift64s(s) >> 11) * (1.0 / 9007199254740992.0);
+    const uint64_t state = splitmix64(seed) + path * 0x3C6EF372FE94F82Aull; // 2*phi mod 2^64
+    u1 = (double)(splitmix64(state) >> 11) * (1.0 / 9007199254740992.0);
+    u2 = (double)(splitmix64(state + 0x9E3779B97F4A7C15ull) >> 11) * (1.0 / 9007199254740992.0);
 }
 
 // ---- uniform grid over the small spheres of a large scene ----------------------------------------

@@ -104,6 +104,13 @@ def gen_rays_counter(params):
     return rays.reshape(6, n)
 
 
+def path_uniforms(seed, first, n):
+    """The counter generator's (u1, u2) of paths [first, first+n) -> float64 [n][2]."""
+    out = np.zeros((n, 2), dtype=np.float64)
+    lib().oracle_path_uniforms(ctypes.c_uint64(seed), ctypes.c_uint64(first), ctypes.c_uint64(n), _ptr(out, ctypes.c_double))
+    return out
+
+
 def gen_spheres():
     out = np.zeros(128, dtype=np.float32)
     lib().oracle_gen_spheres(_ptr(out))

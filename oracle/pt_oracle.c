@@ -240,8 +240,9 @@ static double mt_double(mt19937 *m) { /* random_sample: 53-bit */
     return (a * 67108864.0 + b) / 9007199254740992.0;
 }
 
-/* counter-based generator of the device ray-generate path: splitmix64 of (seed, path)
- * seeds one xorshift64* stream; two 53-bit draws per path.  Pure integer arithmetic. */
+/* counter-based generator of the device ray-generate path: the two 53-bit uniforms of path p are
+ * outputs 2p+1 and 2p+2 of the SplitMix64 stream seeded with splitmix64(seed) (random access by
+ * state = splitmix64(seed) + 2p*phi).  Pure integer arithmetic.  xorshift64* serves gen_scene. */
 static uint64_t splitmix64(uint64_t x) {
     x += 0x9E3779B97F4A7C15ull;
     x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
@@ -255,10 +256,15 @@ static uint64_t xorshift64s(uint64_t *s) {
     return x * 0x2545F4914F6CDD1Dull;
 }
 static void path_uniforms(uint64_t seed, uint64_t path, double *u1, double *u2) {
-    uint64_t s = splitmix64(seed ^ splitmix64(path));
-    if (s == 0) s = 0x9E3779B97F4A7C15ull;
-    *u1 = (double)(xorshift64s(&s) >> 11) * (1.0 / 9007199254740992.0);
-    *u2 = (double)(xorshift64s(&s) >> 11) * (1.0 / 9007199254740992.0);
+    /* outputs 2p+1 and 2p+2 of the SplitMix64 stream whose state starts at splitmix64(seed) */
+    const uint64_t state = splitmix64(seed) + path * 0x3C6EF372FE94F82Aull; /* 2*phi mod 2^64 */
+    *u1 = (double)(splitmix64(state) >> 11) * (1.0 / 9007199254740992.0);
+    *u2 = (double)(splitmix64(state + 0x9E3779B97F4A7C15ull) >> 11) * (1.0 / 9007199254740992.0);
+}
+
+/* test hook: the uniforms of paths [first, first+n) -> out[2n] (u1, u2 interleaved) */
+void oracle_path_uniforms(uint64_t seed, uint64_t first, uint64_t n, double *out) {
+    for (uint64_t i = 0; i < n; ++i) path_uniforms(seed, first + i, out + 2 * i, out + 2 * i + 1);
 }
 
 /* camera frame of gen_rays (gen_data.py:24-30), all float64 */
