@@ -13,6 +13,9 @@
 //   camera / tent / ray  scripts/gen_data.py:21-75  gen_rays
 #pragma once
 #include <stdint.h>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
 #include <math.h>
 
 #if defined(__HIPCC__)
@@ -367,6 +370,9 @@ inline void camera_init(Camera &c, uint32_t w, uint32_t h) { // gen_data.py:24-3
     cr[2] = c.cx[0] * c.g[1] - c.cx[1] * c.g[0];
     const double cn = norm3(cr[0], cr[1], cr[2]);
     for (int i = 0; i < 3; ++i) c.cy[i] = cr[i] / cn * 0.5135;
+    // camera_ray relies on these (they follow from dir = (0, ., .) and cx = (., 0, 0))
+    if (!(c.cx[1] == 0 && c.cx[2] == 0 && c.cy[0] == 0 && !std::signbit(c.cy[0]) && c.g[0] == 0 && !std::signbit(c.g[0]) &&
+          c.g[1] != 0 && c.g[2] != 0 && c.cx[0] > 0)) abort();
     c.inv_w = 1.0 / (double)w; // correctly rounded (IEEE division on the host); used by the device's fast quotients
     c.inv_h = 1.0 / (double)h;
 }
@@ -404,7 +410,10 @@ APT_HD double tent(double u) {
     const double r = 2 * u;
     const bool lower = r < 1;
     const double q = APT_SQRT64(lower ? r : 2 - r);
-    return lower ? q - 1 : 1 - q;
+    // 1 - q is -(q - 1) bit for bit except for q == 1 (u == 0.5 exactly), where it is +0 instead of -0: the only
+    // consumer adds the result to sx + 0.5 >= 0.5, which either zero leaves unchanged.
+    const double t = q - 1;
+    return lower ? t : -t;
 }
 
 struct Ray { float ox, oy, oz, dx, dy, dz; };
@@ -458,9 +467,13 @@ APT_HD void camera_ray(const Camera &c, uint32_t w, uint32_t h, uint32_t i, uint
     double a = xa / (double)w - 0.5;                                             // :41
     double b = xb / (double)h - 0.5;                                             // :42
 #endif
-    double d0 = (c.cx[0] * a + c.cy[0] * b) + c.g[0];
-    double d1 = (c.cx[1] * a + c.cy[1] * b) + c.g[1];
-    double d2 = (c.cx[2] * a + c.cy[2] * b) + c.g[2];
+    // :41-43 d = cx*a + cy*b + g with the reference's camera frame, in which cx = (cx0, 0, 0), cy = (+0, cy1, cy2)
+    // and g = (+0, g1, g2) (camera_init checks it).  The vanishing terms are exact identities, signs of zero
+    // included: a = q - 0.5 is never -0, so cx0*a + (+-0) + (+0) is cx0*a bit for bit; (+-0 + cy1*b) + g1 with
+    // g1 != 0 is cy1*b + g1.  Seven float64 operations per ray less than the general form the oracle keeps.
+    double d0 = c.cx[0] * a;
+    double d1 = c.cy[1] * b + c.g[1];
+    double d2 = c.cy[2] * b + c.g[2];
     double n = APT_SQRT64(norm3_sq(d0, d1, d2));
     rox = (float)(c.pos[0] + d0 * 140);                                      // :45
     roy = (float)(c.pos[1] + d1 * 140);
@@ -500,13 +513,25 @@ APT_HD uint64_t xorshift64s(uint64_t &s) {
     s = x;
     return x * 0x2545F4914F6CDD1Dull;
 }
+// 52 high bits of z as the mantissa of a double in [1, 2), minus 1: a uniform multiple of 2^-52 in [0, 1) with
+// two integer operations and one exact subtraction (a u64 -> f64 conversion costs six float64-class operations).
+APT_HD double unit_from_bits(uint64_t z) {
+    const uint64_t b = (z >> 12) | 0x3FF0000000000000ull;
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __longlong_as_double((long long)b) - 1.0;
+#else
+    double d;
+    memcpy(&d, &b, sizeof d);
+    return d - 1.0;
+#endif
+}
 // The two uniforms of path p are outputs 2p+1 and 2p+2 of ONE SplitMix64 generator (state += phi; output =
 // mix(state)) whose state starts at splitmix64(seed): every path reads its own two consecutive outputs of the
-// same well-tested stream by random access, state(p) = splitmix64(seed) + 2p*phi.  53 high bits each.
+// same well-tested stream by random access, state(p) = splitmix64(seed) + 2p*phi.  52 high bits each.
 APT_HD void path_uniforms(uint64_t seed, uint64_t path, double &u1, double &u2) {
     const uint64_t state = splitmix64(seed) + path * 0x3C6EF372FE94F82Aull; // 2*phi mod 2^64
-    u1 = (double)(splitmix64(state) >> 11) * (1.0 / 9007199254740992.0);
-    u2 = (double)(splitmix64(state + 0x9E3779B97F4A7C15ull) >> 11) * (1.0 / 9007199254740992.0);
+    u1 = unit_from_bits(splitmix64(state));
+    u2 = unit_from_bits(splitmix64(state + 0x9E3779B97F4A7C15ull));
 }
 
 // ---- uniform grid over the small spheres of a large scene ----------------------------------------

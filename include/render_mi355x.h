@@ -121,7 +121,7 @@ int render_do_ex(const apt_render_params *p, void *stream,
 
 /* ---- rays generated on the device, samples accumulated on the device ----------------
  * Fuses gen_rays (scripts/gen_data.py:21-75, camera maths in float64; the two uniforms of path p
- * are outputs 2p+1 and 2p+2 of the SplitMix64 stream seeded with splitmix64(p->seed) -- 53 high
+ * are outputs 2p+1 and 2p+2 of the SplitMix64 stream seeded with splitmix64(p->seed) -- 52 high
  * bits each -- instead of the host MT19937 stream), the render loop
  * (src/render.cpp:104-207) and decode_color (scripts/data_visualization.py:20-59: mean
  * over S, sum over the 2x2 sub-pixels in float64, /4, clip, *255 truncation).

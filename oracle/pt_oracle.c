@@ -240,7 +240,7 @@ static double mt_double(mt19937 *m) { /* random_sample: 53-bit */
     return (a * 67108864.0 + b) / 9007199254740992.0;
 }
 
-/* counter-based generator of the device ray-generate path: the two 53-bit uniforms of path p are
+/* counter-based generator of the device ray-generate path: the two 52-bit uniforms of path p are
  * outputs 2p+1 and 2p+2 of the SplitMix64 stream seeded with splitmix64(seed) (random access by
  * state = splitmix64(seed) + 2p*phi).  Pure integer arithmetic.  xorshift64* serves gen_scene. */
 static uint64_t splitmix64(uint64_t x) {
@@ -255,11 +255,17 @@ static uint64_t xorshift64s(uint64_t *s) {
     *s = x;
     return x * 0x2545F4914F6CDD1Dull;
 }
+static double unit_from_bits(uint64_t z) { /* 52 high bits as the mantissa of a double in [1,2), minus 1 */
+    const uint64_t b = (z >> 12) | 0x3FF0000000000000ull;
+    double d;
+    memcpy(&d, &b, sizeof d);
+    return d - 1.0;
+}
 static void path_uniforms(uint64_t seed, uint64_t path, double *u1, double *u2) {
     /* outputs 2p+1 and 2p+2 of the SplitMix64 stream whose state starts at splitmix64(seed) */
     const uint64_t state = splitmix64(seed) + path * 0x3C6EF372FE94F82Aull; /* 2*phi mod 2^64 */
-    *u1 = (double)(splitmix64(state) >> 11) * (1.0 / 9007199254740992.0);
-    *u2 = (double)(splitmix64(state + 0x9E3779B97F4A7C15ull) >> 11) * (1.0 / 9007199254740992.0);
+    *u1 = unit_from_bits(splitmix64(state));
+    *u2 = unit_from_bits(splitmix64(state + 0x9E3779B97F4A7C15ull));
 }
 
 /* test hook: the uniforms of paths [first, first+n) -> out[2n] (u1, u2 interleaved) */
