@@ -35,12 +35,35 @@ def flops_per_segment(ns):
     return 20 * ns + 33                       # add/sub/mul/div/sqrt = 1 each
 
 
+def effective_cpus():
+    """Host threads this process may really use: the affinity mask and the cgroup CPU quota both count (a GPU box
+    hands one job a share of the host's cores; oversubscribing them makes the OpenMP port slower, not faster)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                quota, period = txt[0], int(txt[1])
+            else:
+                quota, period = txt[0], int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota not in ("max", "-1"):
+                n = min(n, max(1, int(quota) // period))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
+
+
 def cpu_baseline(budget_s=12.0):
     """The oracle (kind "port": the reference's own CPU path needs Huawei CANN and cannot be
     built) on all host threads, on as many 4096-pixel chunks of the C2 frame as fit in
     ~budget_s seconds.  Checker code: imported here only to be TIMED as the baseline."""
     from oracle import oracle
-    threads = min(oracle.max_threads(), os.cpu_count() or 1)
+    threads = min(oracle.max_threads(), effective_cpus())
     sph = oracle.gen_spheres()
     p = oracle.make_params(W, H, S, depth=D, num_spheres=NS, mode=oracle.MODE_K, seed=0)
     chunk, done, seg = 4096, 0, 0
