@@ -497,6 +497,79 @@ __global__ __launch_bounds__(kBlock) void decode_color_kernel(const float *__res
     }
 }
 
+// Same result with coalesced loads (samples >= 8): 8 lanes share one sub-pixel row, lane j owns numpy's accumulator
+// r[j] (elements j, 8+j, ...), so one load instruction of the wave reads 8 x 32 contiguous bytes instead of 64
+// separate rows; the tree is a 3-step butterfly, the n % 8 tail is added in order through shuffles, leaves above
+// 128 samples combine through a per-group LDS stack (the accumulation skeleton of render_frame_kernel).  The 4
+// sub-pixel groups of a (pixel, channel) are adjacent in the wave and are summed in float64 in sub-pixel order.
+__global__ __launch_bounds__(kBlock) void decode_color_kernel8(const float *__restrict__ colors, uint32_t samples,
+                                                               uint64_t npix, LeafProg lp, float *__restrict__ fb,
+                                                               uint8_t *__restrict__ fb_u8) {
+    __shared__ float stack_lds[kMaxStack * kStackSlots];
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t j = threadIdx.x & 7u;
+    const uint32_t sub = (threadIdx.x >> 3) & 3u;
+    const uint32_t slot = threadIdx.x >> 3;
+    const uint64_t n_total = npix * 4 * samples;
+    const uint64_t items = 3 * npix, per_block = kBlock / 32;          // (pixel, channel) pairs, channel-major
+    const uint64_t rounds = (items + per_block * gridDim.x - 1) / (per_block * gridDim.x);
+    // grid-stride over the (pixel, channel) pairs: a block is a few KB of work per round, so the grid is sized to
+    // the machine and loops (a block per pair-group would be bound by the workgroup dispatch rate)
+    for (uint64_t r = 0; r < rounds; ++r) {
+    const uint64_t pc = (r * gridDim.x + blockIdx.x) * per_block + (threadIdx.x >> 5);
+    const bool valid = pc < items;
+    const uint64_t ch = valid ? pc / npix : 0, q = valid ? pc % npix : 0;
+    const float *a = colors + ch * n_total + (q * 4 + sub) * samples;
+    float res = 0.0f;
+    uint32_t start = 0;
+    int sp = 0;
+    for (uint32_t leaf = 0; leaf < lp.nleaves; ++leaf) {
+        const uint32_t n = lp.len(leaf), nfull = n & ~7u;
+        // a leaf has at most 128 samples = 16 per lane: all loads of the lane are issued before the first add
+        // (the rolled loop had one 4-byte load in flight per lane and reached 3.9 TB/s)
+        float v[16];
+#pragma unroll
+        for (int m = 0; m < 16; ++m) v[m] = (8u * m < nfull) ? a[start + 8u * m + j] : 0.0f; // wave-uniform guard
+        float acc = v[0];
+#pragma unroll
+        for (int m = 1; m < 16; ++m)
+            if (8u * m < nfull) acc = acc + v[m];
+        acc = acc + __shfl_xor(acc, 1, 64); // ((r0+r1)+(r2+r3)) + ((r4+r5)+(r6+r7))
+        acc = acc + __shfl_xor(acc, 2, 64);
+        acc = acc + __shfl_xor(acc, 4, 64);
+        const uint32_t nt = n - nfull;
+        if (nt) { // res += a[i] for the n % 8 trailing samples, in order
+            const float c = a[start + nfull + (j < nt ? j : 0)];
+            for (uint32_t t = 0; t < nt; ++t) acc = acc + __shfl(c, (int)((lane & ~7u) + t), 64);
+        }
+        start += n;
+        if (lp.nleaves == 1) {
+            res = acc;
+        } else { // pairwise(left) + pairwise(right), innermost first; the 8 lanes of a group hold equal values
+            stack_lds[sp * kStackSlots + slot] = acc;
+            ++sp;
+            for (uint32_t m = 0; m < lp.ncomb(leaf); ++m) {
+                --sp;
+                const float x = stack_lds[(sp - 1) * kStackSlots + slot], y = stack_lds[sp * kStackSlots + slot];
+                stack_lds[(sp - 1) * kStackSlots + slot] = x + y;
+            }
+        }
+    }
+    if (lp.nleaves > 1) res = stack_lds[slot];
+    const float mean = res / (float)samples;              // np.mean: float32 sum / count
+    const int gbase = (int)(lane & ~31u);
+    double acc64 = 0.0;                                    // data_visualization.py:38 sum_color = zeros (float64)
+#pragma unroll
+    for (int sq = 0; sq < 4; ++sq) acc64 = acc64 + (double)__shfl(mean, gbase + sq * 8, 64); // :41-45
+    const double v = acc64 / 4;                            // :46
+    const double cl = v < 0 ? 0 : (v > 1 ? 1 : v);         // :54
+    if (valid && (lane & 31u) == 0) {
+        fb[ch * npix + q] = (float)cl;
+        if (fb_u8) fb_u8[q * 3 + ch] = (uint8_t)(cl * 255); // :55-57 truncation
+    }
+    }
+}
+
 // ---- kernel: exhaustive self-test of the fast correctly-rounded sqrt ------------------------
 // Every float bit pattern in [begin, begin+count): variant(x) must equal sqrtf(x) bit for bit
 // (any NaN == any NaN) unless the variant asks for the fallback (|x| < 2^-96), in which case the

@@ -8,6 +8,7 @@
 // this is branchy fp32 VALU work whose separately rounded mul/add an MFMA chain could not reproduce.
 // Built with -ffp-contract=off -fno-slp-vectorize (Makefile); see DESIGN.md sections 2 and 4.
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -312,11 +313,16 @@ int apt_decode_color_device(const apt_render_params *p, void *stream, const floa
     LeafProg lp;
     if ((rc = make_leaf_prog(p->samples, lp))) return rc;
     const uint64_t npix = (uint64_t)p->width * p->height;
-    const uint64_t lanes = npix * 3 * 4;
+    const bool wide = p->samples >= 8;                    // 8 lanes per sub-pixel row: coalesced loads
+    const uint64_t lanes = npix * 3 * 4 * (wide ? 8 : 1);
     const uint64_t blocks = (lanes + kBlock - 1) / kBlock;
     if (blocks > 0x7fffffffull) return fail(APT_ERR_ARG, "image too large for one launch%s");
-    hipLaunchKernelGGL(decode_color_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, colors,
-                       p->samples, npix, lp, fb, fb_u8);
+    if (wide)
+        hipLaunchKernelGGL(decode_color_kernel8, dim3((unsigned)std::min<uint64_t>(blocks, 256u * 64u)), dim3(kBlock), 0, (hipStream_t)stream, colors,
+                           p->samples, npix, lp, fb, fb_u8);
+    else
+        hipLaunchKernelGGL(decode_color_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, colors,
+                           p->samples, npix, lp, fb, fb_u8);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? APT_OK : hip_fail(e);
 }
