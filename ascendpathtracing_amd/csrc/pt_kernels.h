@@ -402,46 +402,67 @@ __device__ __forceinline__ uint32_t mt_temper(uint32_t y) {
     return y;
 }
 
+constexpr int kMtGroup = 8; // output blocks tempered into LDS before the rays of their 8*156 paths are made
+
 __global__ __launch_bounds__(kBlock) void gen_rays_mt_kernel(const uint32_t *__restrict__ checkpoints, uint32_t stride,
                                                              uint64_t num_blocks, Camera cam, uint32_t width,
                                                              uint32_t height, uint32_t samples, uint64_t n_total,
                                                              uint64_t begin, uint64_t end, float *__restrict__ rays) {
     __shared__ uint32_t mt[kMtN];
+    __shared__ uint32_t outw[kMtGroup * kMtN]; // tempered output words of up to kMtGroup consecutive blocks (20 KB)
     const uint64_t cb = (uint64_t)blockIdx.x * stride;         // first output block of this workgroup
     for (int i = threadIdx.x; i < kMtN; i += kBlock) mt[i] = checkpoints[(uint64_t)blockIdx.x * kMtN + i];
     __syncthreads();
     const uint64_t last = min(cb + stride, num_blocks);
-    for (uint64_t blk = cb; blk < last; ++blk) {
-        if (blk != cb) { // twist to the next block
-            const int t = threadIdx.x;
-            const int lo[3] = {0, 227, 454}, hi[3] = {227, 454, 624};
+    for (uint64_t g0 = cb; g0 < last; g0 += kMtGroup) {
+        const uint32_t nb = (uint32_t)min((uint64_t)kMtGroup, last - g0);
+        for (uint32_t bl = 0; bl < nb; ++bl) {
+            if (g0 + bl != cb) { // twist to the next block
+                const int t = threadIdx.x;
+                const int lo[3] = {0, 227, 454}, hi[3] = {227, 454, 624};
 #pragma unroll
-            for (int ph = 0; ph < 3; ++ph) {
-                const int i = lo[ph] + t;
-                uint32_t v = 0;
-                const bool on = i < hi[ph];
-                if (on) {
-                    const uint32_t y = (mt[i] & 0x80000000u) | (mt[(i + 1) % kMtN] & 0x7fffffffu);
-                    v = mt[(i + kMtM) % kMtN] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+                for (int ph = 0; ph < 3; ++ph) {
+                    const int i = lo[ph] + t;
+                    uint32_t v = 0;
+                    const bool on = i < hi[ph];
+                    if (on) {
+                        const uint32_t y = (mt[i] & 0x80000000u) | (mt[(i + 1) % kMtN] & 0x7fffffffu);
+                        v = mt[(i + kMtM) % kMtN] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+                    }
+                    __syncthreads();
+                    if (on) mt[i] = v;
+                    __syncthreads();
                 }
-                __syncthreads();
-                if (on) mt[i] = v;
-                __syncthreads();
             }
+            for (int i = threadIdx.x; i < kMtN; i += kBlock) outw[bl * kMtN + i] = mt_temper(mt[i]);
         }
-        const uint64_t p = blk * kPathsPerBlock + threadIdx.x;
-        if (threadIdx.x < kPathsPerBlock && p >= begin && p < end) {
-            const uint32_t a1 = mt_temper(mt[4 * threadIdx.x]) >> 5, b1 = mt_temper(mt[4 * threadIdx.x + 1]) >> 6;
-            const uint32_t a2 = mt_temper(mt[4 * threadIdx.x + 2]) >> 5, b2 = mt_temper(mt[4 * threadIdx.x + 3]) >> 6;
+        __syncthreads();
+        // The camera maths (float64, the expensive part) runs over the group's nb*156 paths with all 256 threads:
+        // one block at a time would keep 156 of them busy.  Path coordinates from the group's base with 32-bit
+        // divisions (p itself needs 64 bits; p / samples and the pixel index normally do not).
+        const uint64_t pbase = g0 * kPathsPerBlock;
+        const uint64_t rb = pbase / samples;
+        const uint32_t kb = (uint32_t)(pbase - rb * samples);
+        const uint32_t npaths = nb * kPathsPerBlock;
+        for (uint32_t q = threadIdx.x; q < npaths; q += kBlock) {
+            const uint64_t p = pbase + q;
+            if (p < begin || p >= end) continue;
+            const uint4 w4 = *reinterpret_cast<const uint4 *>(&outw[4 * q]);
+            const uint32_t a1 = w4.x >> 5, b1 = w4.y >> 6, a2 = w4.z >> 5, b2 = w4.w >> 6;
             const double u1 = ((double)a1 * 67108864.0 + (double)b1) / 9007199254740992.0; // random_sample
             const double u2 = ((double)a2 * 67108864.0 + (double)b2) / 9007199254740992.0;
-            uint32_t i, j, sy, sx;
-            path_coords(p, height, samples, i, j, sy, sx);
+            const uint64_t r = rb + (kb + q) / samples;      // p / samples  (gen_data.py:32-36)
+            const uint32_t sx = (uint32_t)(r & 1), sy = (uint32_t)((r >> 1) & 1);
+            const uint64_t r4 = r >> 2;
+            uint32_t i, j;
+            if (r4 <= 0xffffffffull) { i = (uint32_t)r4 / height; j = (uint32_t)r4 - i * height; }
+            else { i = (uint32_t)(r4 / height); j = (uint32_t)(r4 % height); }
             float rox, roy, roz, rdx, rdy, rdz;
             camera_ray(cam, width, height, i, j, sy, sx, u1, u2, rox, roy, roz, rdx, rdy, rdz);
             rays[p] = rox; rays[n_total + p] = roy; rays[2 * n_total + p] = roz;
             rays[3 * n_total + p] = rdx; rays[4 * n_total + p] = rdy; rays[5 * n_total + p] = rdz;
         }
+        __syncthreads(); // outw is rewritten by the next group
     }
 }
 
