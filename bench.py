@@ -29,6 +29,7 @@ sys.path.insert(0, ROOT)
 W, H, S, D, NS = 1920, 1080, 64, 8, 8
 PEAK_FP32_TFLOPS = 157.3                      # MI355X_MICROARCH.md: vector fp32 (== f32 MFMA) peak, FMA counted as 2
 PEAK_NOFMA_TOPS = 78.6                        # same lanes with FMA forbidden by bit-parity
+MEASURED_NOFMA_TOPS = 68.6                    # v_pk_add/mul_f32 issue rate measured on MI355X (profiles/microbench/valu_rates_mi355x.txt)
 
 
 def flops_per_segment(ns):
@@ -202,6 +203,7 @@ def main():
         "roofline": {"bound": "valu", "kernel": "render_frame_kernel<K,ns8,group8>", "achieved": round(achieved, 3),
                      "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_TFLOPS, 4),
                      "frac_of_nofma_peak": round(achieved / PEAK_NOFMA_TOPS, 4),
+                     "frac_of_measured_nofma_ceiling": round(achieved / MEASURED_NOFMA_TOPS, 4),
                      "flops_per_segment": flops_per_segment(NS), "kernel_ms": round(kern_ms, 3),
                      "traffic": apt_dist.recorded_traffic(ROOT)},
         "target_mray_per_gpu": 100.0,
