@@ -32,8 +32,10 @@ if "SQ_INSTS_VALU" in pmc and "SQ_WAVES" in pmc:
         out["simd_cycles_per_valu_inst"] = pmc["GRBM_GUI_ACTIVE"]["avg"] / 8 * 1024 / pmc["SQ_INSTS_VALU"]["avg"]
 if "GRBM_GUI_ACTIVE" in pmc:
     cyc = pmc["GRBM_GUI_ACTIVE"]["avg"] / 8                      # shader cycles of the launch
-    if "SQ_ACTIVE_INST_VALU" in pmc:                            # rocprof's gfx9 VALUBusy: 100*SQ_ACTIVE_INST_VALU*4/SIMD_NUM/GRBM_GUI_ACTIVE
-        out["valu_busy_pct"] = 100.0 * pmc["SQ_ACTIVE_INST_VALU"]["avg"] * 4 / 4 / (cyc * 256)
+    if "SQ_INSTS_VALU" in pmc:                                  # issue rate per SIMD (1024 SIMDs); the derived "VALUBusy" of
+        out["valu_insts_per_simd_cycle"] = pmc["SQ_INSTS_VALU"]["avg"] / (cyc * 1024)   # older tools exceeds 100 % here, not reported
+    if "SQ_THREAD_CYCLES_VALU" in pmc and "SQ_ACTIVE_INST_VALU" in pmc:   # fraction of the 64 lanes active per VALU instruction
+        out["valu_lane_activity"] = pmc["SQ_THREAD_CYCLES_VALU"]["avg"] / (pmc["SQ_ACTIVE_INST_VALU"]["avg"] * 64)
     if "SQ_WAVE_CYCLES" in pmc:                                 # quad-cycles a wave is resident, summed -> mean waves per SIMD
         out["mean_waves_per_simd"] = pmc["SQ_WAVE_CYCLES"]["avg"] * 4 / (cyc * 1024)
         out["occupancy_pct_of_8_waves"] = 100.0 * out["mean_waves_per_simd"] / 8
