@@ -188,3 +188,21 @@ def test_c_abi_argument_validation_needs_no_gpu(apt):
     assert L.apt_build_grid_host(None, 8, None, None) == 1
     e = apt.make_params(16, 16, 1, path_begin=1024, path_count=0)                           # empty range is a no-op, not an error
     assert L.render_do_ex(ctypes.byref(e), None, one, one, one) == 0
+
+
+def test_header_is_plain_c_and_links_from_c(apt, tmp_path):
+    """include/render_mi355x.h must be usable from a C99 translation unit (the reference's host is C++, a cgo / FFI
+    binding wants plain C): compile with -pedantic, link against the library, run the host-only entry points."""
+    import subprocess
+    src = tmp_path / "abi_c.c"
+    src.write_text('#include "render_mi355x.h"\n#include <stdio.h>\n'
+                   'int main(void) {\n  apt_render_params p; float sph[128];\n  apt_default_params(&p);\n'
+                   '  if (apt_gen_spheres_host(sph)) return 2;\n'
+                   '  printf("%u %u %u %u %d %g\\n", p.width, p.height, p.samples, p.depth, apt_abi_version(), sph[6]);\n'
+                   '  return p.struct_size == sizeof p ? 0 : 1;\n}\n')
+    libdir = os.path.dirname(apt._lib.LIB_PATH)
+    exe = tmp_path / "abi_c"
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"), str(src),
+                    "-o", str(exe), "-L", libdir, "-lrender_mi355x", "-Wl,-rpath," + libdir], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()
+    assert out == ["16", "16", "1", "5", "1", "272.25"]
