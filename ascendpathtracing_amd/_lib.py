@@ -17,7 +17,14 @@ APT_FLAG_EMISSION = 4
 ABI_SYMBOLS = ["apt_default_params", "render_do", "apt_set_default_params", "render_do_ex", "render_frame",
                "apt_gen_rays_device", "apt_decode_color_device", "apt_gen_rays_host", "apt_gen_spheres_host",
                "apt_gen_scene_host", "apt_write_ppm", "apt_abi_version", "apt_last_error", "apt_device_count",
-               "apt_set_trace_counter", "apt_selftest_sqrt", "apt_selftest_div3", "apt_set_refill_lanes", "apt_test_scene", "apt_mt19937_checkpoints_host", "apt_gen_rays_mt_device", "apt_build_grid_host"]
+               "apt_set_trace_counter", "apt_selftest_sqrt", "apt_selftest_div3", "apt_set_refill_lanes", "apt_test_scene", "apt_mt19937_checkpoints_host", "apt_gen_rays_mt_device", "apt_build_grid_host",
+               "apt_last_status", "apt_render_do", "apt_render_host", "apt_context_create", "apt_context_destroy",
+               "apt_context_set_params", "apt_context_set_trace_counter", "apt_context_set_refill_lanes",
+               "apt_context_render_do", "apt_context_render_do_ex", "apt_context_render_frame",
+               "apt_multi_create", "apt_multi_render", "apt_multi_destroy"]
+# the reference declares render_do with C++ linkage (src/main.cpp:9-10): the mangled symbol is exported too
+CXX_RENDER_DO = "_Z9render_dojPvS_PhS0_S0_"
+ABI_VERSION = 2
 
 
 class AptError(RuntimeError):
@@ -69,9 +76,15 @@ def lib():
         h.apt_last_error.restype = ctypes.c_char_p
         h.render_do.restype = None
         h.apt_default_params.restype = None
-        for name in ABI_SYMBOLS:
+        for name in ABI_SYMBOLS + [CXX_RENDER_DO]:
             getattr(h, name)
-        if h.apt_abi_version() != 1:
+        h.apt_context_create.restype = ctypes.c_void_p
+        h.apt_context_destroy.restype = None
+        h.apt_context_render_do.restype = None
+        h.apt_render_do.restype = None
+        h.apt_multi_destroy.restype = None
+        getattr(h, CXX_RENDER_DO).restype = None
+        if h.apt_abi_version() != ABI_VERSION:
             raise AptError("librender_mi355x.so ABI version mismatch")
         _lib = h
     return _lib

@@ -13,10 +13,45 @@
 #include <cstdlib>
 #include <vector>
 
+#include <string>
+
 #include "../../include/render_mi355x.h"
+#include "apt_host.h"
 #include "pt_core.h"
 
+// ---- error record and contexts (apt_host.h) ---------------------------------------------------------
 namespace {
+thread_local std::string t_err;
+thread_local int t_status = APT_OK;
+} // namespace
+
+namespace apt {
+void clear_error() { t_err.clear(); t_status = APT_OK; }
+int set_error(int code, const char *fmt, const char *detail) {
+    char buf[256];
+    snprintf(buf, sizeof buf, fmt, detail);
+    t_err = buf;
+    t_status = code;
+    return code;
+}
+apt_context &default_context() {
+    static apt_context ctx;
+    return ctx;
+}
+} // namespace apt
+
+apt_context::apt_context() {
+    apt_default_params(&v_.params);
+    v_.trace_counter = nullptr;
+    v_.refill_lanes = apt::kDefaultRefillLanes;
+}
+apt_context::Values apt_context::snapshot() { std::lock_guard<std::mutex> g(m_); return v_; }
+void apt_context::set_params(const apt_render_params &p) { std::lock_guard<std::mutex> g(m_); v_.params = p; }
+void apt_context::set_trace_counter(unsigned long long *c) { std::lock_guard<std::mutex> g(m_); v_.trace_counter = c; }
+void apt_context::set_refill_lanes(uint32_t lanes) { std::lock_guard<std::mutex> g(m_); v_.refill_lanes = lanes; }
+
+namespace {
+using apt::set_error;
 
 // np.random.seed(s); np.random.rand(): MT19937 (init_genrand) and the 53-bit
 // random_sample construction ((a >> 5) * 2^26 + (b >> 6)) / 2^53.
@@ -79,8 +114,23 @@ size_t padded_floats(size_t n) { return (n + 127) / 128 * 128; } // gen_data.py:
 
 extern "C" {
 
+const char *apt_last_error(void) { return t_err.c_str(); }
+int apt_last_status(void) { return t_status; }
+
+void apt_default_params(apt_render_params *p) {
+    if (!p) return;
+    memset(p, 0, sizeof *p);
+    p->struct_size = sizeof *p;
+    p->width = 16; p->height = 16; p->samples = 1; // common.h:4-6
+    p->depth = 5;                                   // render.cpp:141
+    p->num_spheres = 8; p->light_index = 7;         // common.h:10, rt_helper.h:776
+    p->eps = 1e-4f; p->gain = 12.0f;                // common.h:9, render.cpp:194
+    p->mode = APT_MODE_KERNEL;
+}
+
 int apt_gen_rays_host(uint32_t width, uint32_t height, uint32_t samples, uint32_t seed, float *rays) {
-    if (!rays || !width || !height || !samples) return APT_ERR_ARG;
+    apt::clear_error();
+    if (!rays || !width || !height || !samples) return set_error(APT_ERR_ARG, "apt_gen_rays_host: rays must be non-null, width/height/samples non-zero%s");
     Mt19937 rng(seed); // np.random.seed(0): gen_data.py:438
     apt::Camera cam;
     apt::camera_init(cam, width, height);
@@ -105,7 +155,8 @@ int apt_gen_rays_host(uint32_t width, uint32_t height, uint32_t samples, uint32_
 // b+1 twists; checkpoint i is that raw state for block i*stride.  Sequential by nature; done once
 // per (seed, length) and reusable for every shorter length.
 int apt_mt19937_checkpoints_host(uint32_t seed, uint64_t num_blocks, uint32_t stride, uint32_t *states) {
-    if (!states || stride == 0 || num_blocks == 0) return APT_ERR_ARG;
+    apt::clear_error();
+    if (!states || stride == 0 || num_blocks == 0) return set_error(APT_ERR_ARG, "apt_mt19937_checkpoints_host: states must be non-null, stride and num_blocks non-zero%s");
     uint32_t mt[624];
     mt[0] = seed;
     for (int i = 1; i < 624; ++i) mt[i] = 1812433253u * (mt[i - 1] ^ (mt[i - 1] >> 30)) + (uint32_t)i;
@@ -120,7 +171,8 @@ int apt_mt19937_checkpoints_host(uint32_t seed, uint64_t num_blocks, uint32_t st
 }
 
 int apt_gen_spheres_host(float *spheres128) {
-    if (!spheres128) return APT_ERR_ARG;
+    apt::clear_error();
+    if (!spheres128) return set_error(APT_ERR_ARG, "apt_gen_spheres_host: spheres128 is null%s");
     memset(spheres128, 0, 128 * sizeof(float));
     for (int k = 0; k < 8; ++k) {
         float rec[10];
@@ -131,7 +183,8 @@ int apt_gen_spheres_host(float *spheres128) {
 }
 
 int apt_gen_scene_host(uint32_t num_spheres, uint64_t seed, float *spheres, size_t *out_floats) {
-    if (num_spheres < 8) return APT_ERR_SCENE;
+    apt::clear_error();
+    if (num_spheres < 8) return set_error(APT_ERR_SCENE, "apt_gen_scene_host: needs num_spheres >= 8 (six walls, at least one sphere, the light)%s");
     const size_t total = padded_floats((size_t)num_spheres * 10);
     if (out_floats) *out_floats = total;
     if (!spheres) return APT_OK;
@@ -167,7 +220,8 @@ int apt_gen_scene_host(uint32_t num_spheres, uint64_t seed, float *spheres, size
 // cell that lists the sphere (the formula's absolute error on disc is ~1e-3 at these coordinates; the
 // margin is 0.05 + 1e-4 * coordinate scale).  Cells are sized for ~1 sphere centre each (APT_GRID_SPHERES_PER_CELL overrides: tuning knob).
 int apt_build_grid_host(const float *sph, uint32_t ns, void *grid, size_t *out_bytes) {
-    if (!sph || ns == 0 || !out_bytes) return APT_ERR_ARG;
+    apt::clear_error();
+    if (!sph || ns == 0 || !out_bytes) return set_error(APT_ERR_ARG, "apt_build_grid_host: spheres/out_bytes must be non-null, num_spheres non-zero%s");
     const float *r2 = sph, *cx = sph + ns, *cy = sph + 2 * (size_t)ns, *cz = sph + 3 * (size_t)ns;
     std::vector<float> rad(ns);
     for (uint32_t k = 0; k < ns; ++k) rad[k] = std::sqrt(std::max(r2[k], 0.0f));
@@ -252,9 +306,10 @@ int apt_build_grid_host(const float *sph, uint32_t ns, void *grid, size_t *out_b
 // = image row y = h-1-i and file column j = x.  It only stays in range for w == h; the
 // non-square case is defined here the evident way, h rows of w pixels.
 int apt_write_ppm(const char *path, uint32_t width, uint32_t height, const uint8_t *fb_u8) {
-    if (!path || !fb_u8 || !width || !height) return APT_ERR_ARG;
+    apt::clear_error();
+    if (!path || !fb_u8 || !width || !height) return set_error(APT_ERR_ARG, "apt_write_ppm: path/fb_u8 must be non-null, width/height non-zero%s");
     FILE *f = fopen(path, "w");
-    if (!f) return APT_ERR_IO;
+    if (!f) return set_error(APT_ERR_IO, "apt_write_ppm: cannot open %s", path);
     fprintf(f, "P3\n%u %u\n255\n", width, height);
     for (uint32_t row = 0; row < height; ++row) {
         const uint32_t y = height - 1 - row;
@@ -264,7 +319,7 @@ int apt_write_ppm(const char *path, uint32_t width, uint32_t height, const uint8
         }
         fprintf(f, "\n");
     }
-    return fclose(f) == 0 ? APT_OK : APT_ERR_IO;
+    return fclose(f) == 0 ? APT_OK : set_error(APT_ERR_IO, "apt_write_ppm: write to %s failed", path);
 }
 
 } // extern "C"

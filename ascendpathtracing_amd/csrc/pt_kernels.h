@@ -16,7 +16,8 @@ __global__ __launch_bounds__(kBlock, SC == kSceneGrid ? APT_GRID_WAVES : 1) void
     __shared__ float4 tab[16];
     __shared__ float4 tile[SC == kSceneTiles ? kTile : 1];
     Scene8 sc;
-    if (NS8) load_scene8(sph, sc, tab);
+    Tab8 tab8{tab, tab + 8};
+    if (NS8) tab8 = load_scene8(sph, sc, tab);
     const uint64_t local = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
     const bool valid = local < count;
     const uint64_t p = begin + (valid ? local : 0);
@@ -24,7 +25,7 @@ __global__ __launch_bounds__(kBlock, SC == kSceneGrid ? APT_GRID_WAVES : 1) void
     path_init(s, rays[p], rays[n_total + p], rays[2 * n_total + p], rays[3 * n_total + p], rays[4 * n_total + p],
               rays[5 * n_total + p]);
     uint32_t traced;
-    if (SC == kScene8) traced = trace_ns8<MODE, RETIRE>(sc, tab, s, valid, ta, p);
+    if (SC == kScene8) traced = trace_ns8<MODE, RETIRE>(sc, tab8, s, valid, ta, p);
     else if (SC == kSceneGrid) traced = trace_grid<MODE, RETIRE>(sph, ta.grid, s, valid, ta, p);
     else traced = trace_dyn<MODE, RETIRE>(sph, tile, s, valid, ta, p);
     if (valid) {                                          // render.cpp:194-196, CopyOut :210-223
@@ -49,8 +50,10 @@ __global__ __launch_bounds__(kBlock) void render_paths_queue_kernel(const float 
                                                                     uint64_t begin, uint64_t count, TraceArgs ta) {
     __shared__ float4 tab[16];
     Scene8 sc;
-    load_scene8(sph, sc, tab);
+    const Tab8 tab8 = load_scene8(sph, sc, tab);
     const Gain3 gain = load_gain(sph, ta);
+    const KeyConsts kc = make_key_consts(ta.eps);
+    const bool fast_ok = eps_allows_rootkey(ta.eps);
     const uint64_t wave = (uint64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
     uint64_t next = wave * kQueueChunk;                         // wave-uniform
     const uint64_t end = min(count, next + kQueueChunk);
@@ -80,12 +83,8 @@ __global__ __launch_bounds__(kBlock) void render_paths_queue_kernel(const float 
             continue;
         }
         PathState nx;
-        bool redo = bounce_ns8<MODE, true>(sc, tab, s, nx, ta);
-        redo = redo && active;
-        if (__builtin_expect(__any(redo), 0)) { // exact re-run, see trace_ns8
-            asm volatile("" ::: "memory");
-            (void)bounce_ns8<MODE, false>(sc, tab, s, nx, ta);
-        }
+        uint64_t alive_m = __builtin_amdgcn_ballot_w64(s.alive != 0);
+        bounce_ns8_checked<MODE>(sc, tab8, s, nx, ta, kc, fast_ok, alive_m, true, __builtin_amdgcn_ballot_w64(active));
         if (ta.rr_start && ta.depth - depth_left + 1 >= ta.rr_start) russian_roulette(nx, cur_key, ta.depth - depth_left);
         s = nx;
         traced += active ? 1u : 0u;
@@ -128,8 +127,11 @@ __global__ __launch_bounds__(kBlock, (RETIRE && SC == kScene8 && GROUP == 8) ? 5
     __shared__ Camera cam;
     if (threadIdx.x < sizeof(Camera) / sizeof(double)) (&cam.pos[0])[threadIdx.x] = (&fa.cam.pos[0])[threadIdx.x];
     Scene8 sc;
-    if (NS8) load_scene8(sph, sc, tab);
+    Tab8 tab8{tab, tab + 8};
+    if (NS8) tab8 = load_scene8(sph, sc, tab);
     else __syncthreads();
+    const KeyConsts kc = make_key_consts(ta.eps);      // refill queue only (trace_ns8 makes its own)
+    const bool fast_ok = eps_allows_rootkey(ta.eps);
 
     const uint32_t lane = threadIdx.x & 63;
     const uint64_t L = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -141,7 +143,8 @@ __global__ __launch_bounds__(kBlock, (RETIRE && SC == kScene8 && GROUP == 8) ? 5
     const uint32_t pi = (uint32_t)(q / fa.height), pj = (uint32_t)(q % fa.height);
     const uint32_t sy = sub >> 1, sx = sub & 1;
     const uint64_t pbase = (q * 4 + sub) * fa.samples;
-    uint32_t traced = 0;
+    uint32_t traced = 0;       // segments of this lane's own pixel (gated by `valid` at the end)
+    uint32_t queue_traced = 0; // refill queue: segments this lane traced for ANY valid item of its wave
 
     const Gain3 gain = load_gain(sph, ta);
     struct Col { float r, g, b; };
@@ -152,7 +155,7 @@ __global__ __launch_bounds__(kBlock, (RETIRE && SC == kScene8 && GROUP == 8) ? 5
         camera_ray(cam, fa.width, fa.height, pi, pj, sy, sx, u1, u2, rox, roy, roz, rdx, rdy, rdz);
         PathState s;
         path_init(s, rox, roy, roz, rdx, rdy, rdz);
-        if (SC == kScene8) traced += trace_ns8<MODE, RETIRE>(sc, tab, s, valid, ta, pbase + k);
+        if (SC == kScene8) traced += trace_ns8<MODE, RETIRE>(sc, tab8, s, valid, ta, pbase + k);
         else if (SC == kSceneGrid) traced += trace_grid<MODE, RETIRE>(sph, ta.grid, s, valid, ta, pbase + k);
         else traced += trace_dyn<MODE, RETIRE>(sph, tile, s, valid, ta, pbase + k);
         return Col{s.rx * gain.r, s.ry * gain.g, s.rz * gain.b};
@@ -244,18 +247,14 @@ __global__ __launch_bounds__(kBlock, (RETIRE && SC == kScene8 && GROUP == 8) ? 5
                     }
                     ++n_bounce_exec;
                     PathState nx;
-                    bool redo = bounce_ns8<MODE, true>(sc, tab, s, nx, ta);
-                    redo = redo && active;
-                    if (__builtin_expect(__any(redo), 0)) { // exact re-run, see trace_ns8
-                        asm volatile("" ::: "memory");
-                        (void)bounce_ns8<MODE, false>(sc, tab, s, nx, ta);
-                    }
+                    uint64_t alive_m = __builtin_amdgcn_ballot_w64(s.alive != 0);
+                    bounce_ns8_checked<MODE>(sc, tab8, s, nx, ta, kc, fast_ok, alive_m, true, __builtin_amdgcn_ballot_w64(active));
                     if (ta.rr_start && ta.depth - depth_left + 1 >= ta.rr_start) // 0-based bounce index = depth - depth_left
                         russian_roulette(nx, cur_key, ta.depth - depth_left);
                     // inactive lanes computed on stale state; whatever they hold is overwritten when
                     // they start their next ray, so the update itself needs no mask
                     s = nx;
-                    traced += active ? 1u : 0u;
+                    queue_traced += (active && cur_valid) ? 1u : 0u; // the item's pixel decides, not this lane's own
                     depth_left -= active ? 1u : 0u;
                     if (active && (depth_left == 0 || path_finished(s))) {
                         depth_left = 0;
@@ -342,7 +341,7 @@ __global__ __launch_bounds__(kBlock, (RETIRE && SC == kScene8 && GROUP == 8) ? 5
             if (fa.fb_u8) fa.fb_u8[pl * 3 + ch] = (uint8_t)(cl * 255); // :55-57 truncation
         }
     }
-    count_traced(ta, valid ? traced : 0);
+    count_traced(ta, (valid ? traced : 0) + queue_traced);
 }
 
 // ---- kernel: first-hit debug oracle (gen_data.py:134-188 test_scene) ---------------------------
@@ -409,7 +408,7 @@ __global__ __launch_bounds__(kBlock) void gen_rays_mt_kernel(const uint32_t *__r
                                                              uint32_t height, uint32_t samples, uint64_t n_total,
                                                              uint64_t begin, uint64_t end, float *__restrict__ rays) {
     __shared__ uint32_t mt[kMtN];
-    __shared__ uint32_t outw[kMtGroup * kMtN]; // tempered output words of up to kMtGroup consecutive blocks (20 KB)
+    __shared__ __align__(16) uint32_t outw[kMtGroup * kMtN]; // tempered output words of up to kMtGroup consecutive blocks (20 KB); read back as uint4
     const uint64_t cb = (uint64_t)blockIdx.x * stride;         // first output block of this workgroup
     for (int i = threadIdx.x; i < kMtN; i += kBlock) mt[i] = checkpoints[(uint64_t)blockIdx.x * kMtN + i];
     __syncthreads();

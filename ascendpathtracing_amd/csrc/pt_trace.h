@@ -24,15 +24,21 @@ constexpr int kMaxLeaves = 64;   // pairwise-sum leaves -> samples <= 8192
                          // (dependent cell -> item loads), measured 464 / 371 / 334 / 311 / 302 ms at 3 / 4 / 5 / 6 / 8 waves
 #endif
 #ifndef APT_FULL_WAVES
-#define APT_FULL_WAVES 1 // min waves per SIMD requested for the full-trace frame kernel (A/B knob)
+#define APT_FULL_WAVES 6 // min waves per SIMD requested for the full-trace frame kernel: caps it at 80 VGPRs (the scheduler
+                         // otherwise interleaves three sphere pairs and lands on 81 -> 5 waves)
 #endif
 constexpr int kMaxStack = 8;
 constexpr int kStackSlots = kBlock / 8; // one pairwise-sum stack per sub-pixel group (its 8 lanes hold equal values)
-constexpr uint32_t kRefillLanes = 32; // default: lanes with an empty ray slot that trigger a wave-wide ray-generate
+
 
 struct Scene8 { // wave-uniform registers (SGPRs)
     float cx[8], cy[8], cz[8], r2[8];
 };
+
+// LDS table of the 8-sphere scene: entry k of `geo` = (cx, cy, cz, r2), entry k of `alb` = (albedo, 0); 16 bytes per
+// entry, so that the byte offsets of entry k's index bits (16, 32, 64) are inline constants (bounce_ns8_v2).
+struct Tab8 { const float4 *geo, *alb; };
+constexpr int kTab8Floats4 = 16;
 
 struct TraceArgs {
     uint32_t ns;
@@ -86,7 +92,7 @@ __device__ __forceinline__ HitPre2 intersect_pre2(const float4 a, const float4 c
 // One bounce: 8 intersections (sphere operands in SGPRs), arg-min, gather, shade.
 // FAST: exact fast sqrt sequences (pt_core.h) and, when eps permits, the integer-key arg-min.
 template <int MODE, bool FAST>
-__device__ __forceinline__ bool bounce_ns8(const Scene8 &sc, const float4 *tab, const PathState &s, PathState &n,
+__device__ __forceinline__ bool bounce_ns8(const Scene8 &sc, const Tab8 tab, const PathState &s, PathState &n,
                                            const TraceArgs &ta) {
     float amin = 1.0f; // min |sqrt argument| of this bounce (FAST only)
     float tmin;
@@ -135,41 +141,237 @@ __device__ __forceinline__ bool bounce_ns8(const Scene8 &sc, const float4 *tab, 
         }
     }
     const int g = (idx < 0) ? 7 : idx; // Python index -1 wraps to the last sphere
-    const float4 c = tab[2 * g], col = tab[2 * g + 1];
+    const float4 c = tab.geo[g], col = tab.alb[g];
     n = s;
     shade_and_reflect<MODE, FAST>(n, tmin, c.x, c.y, c.z, col.x, col.y, col.z, idx == ta.light, &amin);
     // the fast sequences are only valid for |sqrt argument| >= 2^-96 and 0 < eps < 1e20
     return FAST && (amin < 0x1p-96f || !eps_allows_rootkey(ta.eps));
 }
 
+// ---- the same bounce with fewer half-rate instructions (APT_BOUNCE_V2, default) ---------------------------
+// On gfx950 a wave64 VALU instruction issues in ~2.5 cycles when it is a plain fp32/int32 operation on VGPRs
+// and in ~4.3 cycles when it is a compare, select, min/max, or has an SGPR operand (profiles/microbench/
+// valu_rates_mi355x.txt); the bounce block is VALU-issue bound, so its time is the sum of those costs.  Same
+// arithmetic as bounce_ns8<MODE, true>, instruction for instruction in the fp32 data path; what changes:
+//   * the root-key bias and start value live in VGPRs (KeyConsts): the 16 integer subtractions per bounce no
+//     longer carry an SGPR operand (half rate -> full rate);
+//   * the arg-min index is not tracked per lane with compare + select per sphere: the 8 "sphere k improved the
+//     minimum" compares write wave masks, three scalar accumulators collect the bits of the index on the SALU
+//     (which issues beside the VALU), and three selects + one or3 turn them into the LDS address of the hit
+//     sphere (16 bytes per entry: 16, 32 and 64 are inline constants);
+//   * the validity tracking of the fast sqrt / divide sequences is v_min3_f32 with |.| source modifiers: one
+//     instruction per sphere pair, two in the shading step;
+//   * the throughput update runs under the alive mask (exec) instead of through three selects;
+//   * "does any lane need the exact re-run" is the OR of two wave masks, not a materialised boolean.
+struct KeyConsts { uint32_t bias, init; };
+__device__ __forceinline__ KeyConsts make_key_consts(float eps) {
+    KeyConsts kc;
+    kc.bias = f32_bits(eps) + 1u;
+    kc.init = f32_bits(kMissT) - kc.bias;
+    asm volatile("" : "+v"(kc.bias), "+v"(kc.init)); // opaque: the compiler must keep them in VGPRs
+    return kc;
+}
+__device__ __forceinline__ float min3_abs(float a, float b, float c) { // min(a, |b|, |c|); NaNs drop out (IEEE minNum)
+    float r;
+    asm("v_min3_f32 %0, %1, |%2|, |%3|" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ uint32_t min3_u32(uint32_t a, uint32_t b, uint32_t c) {
+    uint32_t r;
+    asm("v_min3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ uint32_t select_const(uint64_t mask, uint32_t value_if_set) { // value must be an inline constant
+    uint32_t r;
+    asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(r) : "n"(value_if_set), "s"(mask));
+    return r;
+}
+
+// -> wave mask of the lanes that left the validity range of the fast sequences (exact re-run wanted)
+// `alive`: wave mask of the lanes whose path has not reached the light (in: before, out: after this bounce);
+// s.alive / n.alive are not read or written here (callers that need the per-lane form make it from the mask).
+template <int MODE>
+__device__ __forceinline__ uint64_t bounce_ns8_v2(const Scene8 &sc, const Tab8 tab, const PathState &s, PathState &n,
+                                                  const TraceArgs &ta, const KeyConsts &kc, uint64_t &alive) {
+    float amin = 1.0f;
+    uint32_t best = kc.init;
+    uint64_t b0 = 0, b1 = 0, b2 = 0, any = 0;
+    auto update = [&](float t0, float t1, int k) {
+        const uint32_t m0 = f32_bits(t0) - kc.bias, m1 = f32_bits(t1) - kc.bias;
+        const uint32_t nb = min3_u32(best, m0, m1);
+        const uint64_t better = __builtin_amdgcn_ballot_w64(nb != best); // strict '<': lowest index wins ties
+        best = nb;
+        b0 = (k & 1) ? (b0 | better) : (b0 & ~better);
+        b1 = (k & 2) ? (b1 | better) : (b1 & ~better);
+        b2 = (k & 4) ? (b2 | better) : (b2 & ~better);
+        if (MODE == kModeOracle) any |= better;
+    };
+#pragma unroll
+    for (int k = 0; k < 8; k += 2) { // rt_helper.h:457-467, two spheres per packed instruction
+        const HitPre2 h = intersect_pre2(f2{sc.cx[k], sc.cx[k + 1]}, f2{sc.cy[k], sc.cy[k + 1]}, f2{sc.cz[k], sc.cz[k + 1]},
+                                         f2{sc.r2[k], sc.r2[k + 1]}, s.ox, s.oy, s.oz, s.dx, s.dy, s.dz);
+        amin = min3_abs(amin, h.disc.x, h.disc.y);
+        // sqrt_rn_rsq1 on both lanes of the pair (pt_core.h): y = x*r, hh = r/2, q = fma(fma(-y,y,x), hh, y)
+        const f2 r0 = {__builtin_amdgcn_rsqf(h.disc.x), __builtin_amdgcn_rsqf(h.disc.y)};
+        const f2 y = h.disc * r0, hh = r0 * 0.5f;
+        const f2 res = __builtin_elementwise_fma(-y, y, h.disc);
+        const f2 q = __builtin_elementwise_fma(res, hh, y);
+        const f2 t0 = h.b - q, t1 = h.b + q;
+        update(t0.x, t1.x, k);
+        update(t0.y, t1.y, k + 1);
+    }
+    const float tmin = bits_f32(best + kc.bias);
+    uint64_t light_mask; // lanes whose arg-min is the light
+    if (MODE == kModeOracle) { // all-miss: Python index -1 = the last sphere's geometry and colour, never "the light" (gen_data.py:311,343,390)
+        b0 |= ~any; b1 |= ~any; b2 |= ~any;
+    }
+    uint32_t addr;
+    {
+        const uint32_t a0 = select_const(b0, 16), a1 = select_const(b1, 32), a2 = select_const(b2, 64);
+        asm("v_or3_b32 %0, %1, %2, %3" : "=v"(addr) : "v"(a0), "v"(a1), "v"(a2));
+    }
+    light_mask = __builtin_amdgcn_ballot_w64(addr == (uint32_t)ta.light * 16u); // light < 0 or > 7 never matches
+    if (MODE == kModeOracle) light_mask &= any;
+    const float4 c = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(tab.geo) + addr);
+    const float4 col = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(tab.alb) + addr);
+    // GenerateNewRays (rt_helper.h:504-709), as shade_and_reflect<MODE, true>
+    float hx = s.dx * tmin, hy = s.dy * tmin, hz = s.dz * tmin;
+    hx = s.ox + hx; hy = s.oy + hy; hz = s.oz + hz;
+    const float nx = hx - c.x, ny = hy - c.y, nz = hz - c.z;
+    float len2;
+    if (MODE == kModeOracle) {
+        const float p0 = nx * nx, p1 = ny * ny, p2 = nz * nz;
+        double acc = 0.0 + (double)p0;
+        acc = acc + (double)p1;
+        acc = acc + (double)p2;
+        len2 = (float)acc;
+    } else {
+        float acc = 0.0f + nx * nx;
+        acc = acc + ny * ny;
+        acc = acc + nz * nz;
+        len2 = acc;
+    }
+    amin = min3_abs(amin, len2, nx);            // sqrt_rn_rsq1's and div3_shared's validity, see pt_core.h
+    amin = min3_abs(amin, ny, nz);
+    float L;
+    {
+        const float r0 = __builtin_amdgcn_rsqf(len2);
+        const float y = len2 * r0, h = 0.5f * r0;
+        const float r = __builtin_fmaf(-y, y, len2);
+        L = __builtin_fmaf(r, h, y);
+    }
+    float ux, uy, uz;
+    {   // div3_shared without its own min/flag bookkeeping
+        const float r0 = __builtin_amdgcn_rcpf(L);
+        const float e0 = __builtin_fmaf(-L, r0, 1.0f);
+        const float r = __builtin_fmaf(e0, r0, r0);
+        float q, e;
+        q = nx * r; e = __builtin_fmaf(-L, q, nx); q = __builtin_fmaf(e, r, q); e = __builtin_fmaf(-L, q, nx);
+        ux = __builtin_fmaf(e, r, q);
+        q = ny * r; e = __builtin_fmaf(-L, q, ny); q = __builtin_fmaf(e, r, q); e = __builtin_fmaf(-L, q, ny);
+        uy = __builtin_fmaf(e, r, q);
+        q = nz * r; e = __builtin_fmaf(-L, q, nz); q = __builtin_fmaf(e, r, q); e = __builtin_fmaf(-L, q, nz);
+        uz = __builtin_fmaf(e, r, q);
+    }
+    float dot;
+    if (MODE == kModeOracle) {
+        const float p0 = s.dx * ux, p1 = s.dy * uy, p2 = s.dz * uz;
+        double acc = 0.0 + (double)p0;
+        acc = acc + (double)p1;
+        acc = acc + (double)p2;
+        dot = (float)acc;
+    } else {
+        dot = 0.0f + s.dx * ux;
+        dot = dot + s.dy * uy;
+        dot = dot + s.dz * uz;
+    }
+    const float k2 = dot * 2.0f;
+    const float mx = ux * k2, my = uy * k2, mz = uz * k2;
+    n.dx = s.dx - mx; n.dy = s.dy - my; n.dz = s.dz - mz;
+    n.ox = hx; n.oy = hy; n.oz = hz;
+    // AccumulateIntervalColor (rt_helper.h:711-830): alive &= idx != light; ret *= alive ? albedo : 1
+    alive &= ~light_mask;
+#ifdef APT_T_NCOPY
+    const float ndx = n.dx, ndy = n.dy, ndz = n.dz, nox = n.ox, noy = n.oy, noz = n.oz;
+    n = s;
+    n.dx = ndx; n.dy = ndy; n.dz = ndz; n.ox = nox; n.oy = noy; n.oz = noz;
+#else
+    n.alive = s.alive;
+    n.rx = s.rx; n.ry = s.ry; n.rz = s.rz;
+#endif
+#ifdef APT_T_NOEXEC
+    if (select_const(alive, 1)) { n.rx = col.x * n.rx; n.ry = col.y * n.ry; n.rz = col.z * n.rz; }
+#else
+    {   // the three products under exec = alive (an s_and_saveexec / restore pair instead of three selects)
+        uint64_t saved;
+        asm volatile("s_and_saveexec_b64 %[sv], %[m]\n\t"
+                     "v_mul_f32 %[rx], %[cx], %[rx]\n\t"
+                     "v_mul_f32 %[ry], %[cy], %[ry]\n\t"
+                     "v_mul_f32 %[rz], %[cz], %[rz]\n\t"
+                     "s_mov_b64 exec, %[sv]"
+                     : [sv] "=&s"(saved), [rx] "+v"(n.rx), [ry] "+v"(n.ry), [rz] "+v"(n.rz)
+                     : [m] "s"(alive), [cx] "v"(col.x), [cy] "v"(col.y), [cz] "v"(col.z));
+    }
+#endif
+    const uint64_t tiny = __builtin_amdgcn_ballot_w64(amin < 0x1p-96f);
+    const uint64_t huge = __builtin_amdgcn_ballot_w64((int32_t)(0x5d800000u - f32_bits(len2)) < 0); // len2 > 2^60 (or NaN): see div3_shared
+    return tiny | huge;
+}
+
+// One bounce of a wave through the fast form, falling back to the exact form (sqrtf, '/', float selects) for the
+// whole wave when a lane whose path can still reach an output left the fast sequences' validity range, or when
+// eps does not permit the integer root keys.  `alive` as in bounce_ns8_v2; s.alive is refreshed from it only on
+// the cold path, n.alive is valid on return only if `want_lane_alive`.
+template <int MODE>
+__device__ __forceinline__ void bounce_ns8_checked(const Scene8 &sc, const Tab8 tab, const PathState &s, PathState &n,
+                                                   const TraceArgs &ta, const KeyConsts &kc, bool fast_ok,
+                                                   uint64_t &alive, bool want_lane_alive, uint64_t active = ~0ull) {
+    const uint64_t alive_in = alive;
+    uint64_t redo = ~0ull;
+    if (__builtin_expect(fast_ok, 1)) redo = bounce_ns8_v2<MODE>(sc, tab, s, n, ta, kc, alive);
+#ifndef APT_T_NOCOLD
+    if (__builtin_expect((redo & active) != 0, 0)) {
+        // A lane left the validity range of the fast sequences (|sqrt argument| < 2^-96, divide operands outside
+        // [2^-40, 2^40]).  A lane whose path is already finished (alive bit cleared or throughput zero) cannot
+        // influence any output any more, so its request is ignored: deep all-miss paths (|n| ~ 1e20) are of that
+        // kind.  Otherwise redo the bounce with sqrtf() and '/'.  The empty volatile asm keeps this cold path out
+        // of the hot block.
+        PathState cold = s;
+        cold.alive = select_const(alive_in, 1);
+        const bool lane = select_const(redo & active, 1) != 0 && (!fast_ok || !path_finished(cold));
+        if (__any(lane)) {
+            asm volatile("" ::: "memory");
+            (void)bounce_ns8<MODE, false>(sc, tab, cold, n, ta);
+            alive = __builtin_amdgcn_ballot_w64(n.alive != 0);
+            if (ta.traced && (threadIdx.x & 63) == 0) atomicAdd(ta.traced + 3, 1ull); // statistics: exact re-runs
+        }
+    }
+#endif
+    if (want_lane_alive) n.alive = select_const(alive, 1);
+}
+
 template <int MODE, bool RETIRE>
-__device__ __forceinline__ uint32_t trace_ns8(const Scene8 &sc, const float4 *tab, PathState &s, bool valid,
+__device__ __forceinline__ uint32_t trace_ns8(const Scene8 &sc, const Tab8 tab, PathState &s, bool valid,
                                               const TraceArgs &ta, uint64_t path) {
     uint32_t traced = 0;
     const uint64_t rr_key = ta.rr_start ? rr_path_key(ta.seed, path) : 0;
+    const KeyConsts kc = make_key_consts(ta.eps);
+    const bool fast_ok = eps_allows_rootkey(ta.eps);
+    const bool lane_alive = RETIRE || ta.rr_start != 0;            // who needs s.alive per lane (wave-uniform)
+    uint64_t alive = __builtin_amdgcn_ballot_w64(s.alive != 0);
     for (uint32_t d = 0; d < ta.depth; ++d) { // render.cpp:140-188
         const bool fin = RETIRE && (!valid || path_finished(s));
         if (RETIRE && __all(fin)) break;
         PathState n;
-        bool redo = bounce_ns8<MODE, true>(sc, tab, s, n, ta);
-        if (__builtin_expect(__any(redo), 0)) {
-            // A lane left the validity range of the fast sequences (|sqrt argument| < 2^-96, divide
-            // operands outside [2^-40, 2^40]).  A lane whose path is already finished (alive bit
-            // cleared or throughput zero) cannot influence any output any more, so its request is
-            // ignored: deep all-miss paths (|n| ~ 1e20) are of that kind.  Otherwise redo the bounce
-            // with sqrtf() and '/'.  The empty volatile asm keeps this cold path out of the hot block.
-            redo = redo && !path_finished(s);
-            if (__any(redo)) {
-                asm volatile("" ::: "memory");
-                (void)bounce_ns8<MODE, false>(sc, tab, s, n, ta);
-                if (ta.traced && (threadIdx.x & 63) == 0) atomicAdd(ta.traced + 3, 1ull); // statistics: exact re-runs
-            }
-        }
+        uint64_t alive_n = alive;
+        bounce_ns8_checked<MODE>(sc, tab, s, n, ta, kc, fast_ok, alive_n, lane_alive);
         if (ta.rr_start && d + 1 >= ta.rr_start) russian_roulette(n, rr_key, d); // wave-uniform branch
         if (RETIRE) {
             if (!fin) { s = n; ++traced; }
+            alive = __builtin_amdgcn_ballot_w64(s.alive != 0);
         } else { // full trace: lanes past the end of the range compute garbage that is never stored
             s = n;
+            alive = alive_n;
             ++traced;
         }
     }
@@ -262,6 +464,11 @@ __device__ __forceinline__ uint32_t trace_grid(const float *__restrict__ sph, co
     const float *colx = sph + 7 * (size_t)ns, *coly = sph + 8 * (size_t)ns, *colz = sph + 9 * (size_t)ns;
     const uint64_t rr_key = ta.rr_start ? rr_path_key(ta.seed, path) : 0;
     const int n0 = (int)h.n[0], n1 = (int)h.n[1], n2 = (int)h.n[2];
+    // A grid built for another scene (or a stale / foreign pointer that still carries the magic) would index past
+    // the sphere table: such a buffer is not walked at all -- every sphere is tested straight from the [10][Ns]
+    // planes instead (same image, brute-force speed).  Wave-uniform.
+    const bool grid_ok = h.magic == kGridMagic && h.num_spheres == ns;
+    const float *r2p = sph, *cxp = sph + ns, *cyp = sph + 2 * (size_t)ns, *czp = sph + 3 * (size_t)ns;
     uint32_t traced = 0, n_cells = 0, n_tests = 0; // statistics
     for (uint32_t d = 0; d < ta.depth; ++d) {
         const bool fin = !valid || (RETIRE && path_finished(s));
@@ -312,10 +519,14 @@ __device__ __forceinline__ uint32_t trace_grid(const float *__restrict__ sph, co
             const float t = select_root(hp.b - q, hp.b + q, ta.eps);
             if (t < tmin || (t == tmin && (int)k < idx)) { tmin = t; idx = (int)k; }
         };
-        for (uint32_t i = 0; i < h.nlarge; ++i) { const uint32_t k = large[i]; test_large(geom[k], k); } // wave-uniform: scalar loads
+        if (grid_ok)
+            for (uint32_t i = 0; i < h.nlarge; ++i) { const uint32_t k = large[i]; test_large(geom[k], k); } // wave-uniform: scalar loads
         const float dd = s.dx * s.dx + s.dy * s.dy + s.dz * s.dz;
         const bool unit = fabsf(dd - 1.0f) <= 1e-3f; // false for NaN/inf
-        if (!fin && !unit) {
+        if (!grid_ok) {
+            if (!fin)
+                for (uint32_t k = 0; k < ns; ++k) { ++n_tests; test_geom(make_float4(cxp[k], cyp[k], czp[k], r2p[k]), k); }
+        } else if (!fin && !unit) {
             for (uint32_t k = 0; k < ns; ++k) test(k);
         } else if (!fin) {
             // slab test against the grid box; all DDA state in scalars (no indexed arrays -> no scratch)
@@ -395,7 +606,7 @@ __device__ __forceinline__ uint32_t trace_grid(const float *__restrict__ sph, co
         if (!fin) {
             if (pos != ~0u) idx = (int)items[pos];
             const uint32_t g = (idx < 0) ? ns - 1 : (uint32_t)idx;
-            const float4 gc = geom[g];
+            const float4 gc = grid_ok ? geom[g] : make_float4(cxp[g], cyp[g], czp[g], r2p[g]);
 #if defined(__HIP_DEVICE_COMPILE__)
             {   // exact fast sqrt / shared-reciprocal divide (pt_core.h); out-of-range operands redo the step with sqrtf() and '/'
                 PathState n = s;
@@ -424,17 +635,18 @@ __device__ __forceinline__ uint32_t trace_grid(const float *__restrict__ sph, co
 }
 
 // spheres.bin layout [10][8]: r2, x, y, z, em*3, col*3 (gen_data.py:106-127, rt_helper.h:93-102)
-__device__ __forceinline__ void load_scene8(const float *__restrict__ sph, Scene8 &sc, float4 *tab) {
+__device__ __forceinline__ Tab8 load_scene8(const float *__restrict__ sph, Scene8 &sc, float4 *tab) {
 #pragma unroll
     for (int k = 0; k < 8; ++k) { // constant offsets from a uniform read-only pointer: scalar loads
         sc.r2[k] = sph[k]; sc.cx[k] = sph[8 + k]; sc.cy[k] = sph[16 + k]; sc.cz[k] = sph[24 + k];
     }
     if (threadIdx.x < 8) {
         const int k = threadIdx.x;
-        tab[2 * k] = make_float4(sph[8 + k], sph[16 + k], sph[24 + k], sph[k]);
-        tab[2 * k + 1] = make_float4(sph[56 + k], sph[64 + k], sph[72 + k], 0.0f);
+        tab[k] = make_float4(sph[8 + k], sph[16 + k], sph[24 + k], sph[k]);
+        tab[8 + k] = make_float4(sph[56 + k], sph[64 + k], sph[72 + k], 0.0f);
     }
     __syncthreads();
+    return Tab8{tab, tab + 8};
 }
 
 // render.cpp:194-196 multiplies by the literal 12; with APT_FLAG_EMISSION the light's emission planes

@@ -9,6 +9,7 @@
 // Built with -ffp-contract=off -fno-slp-vectorize (Makefile); see DESIGN.md sections 2 and 4.
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <new>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -17,6 +18,7 @@
 #include <vector>
 
 #include "../../include/render_mi355x.h"
+#include "apt_host.h"
 #include "pt_core.h"
 
 #include "pt_kernels.h"
@@ -24,18 +26,9 @@
 namespace {
 
 // ---- host side ----------------------------------------------------------------------------
-thread_local std::string g_err;
-apt_render_params g_default;
-bool g_default_init = false;
-unsigned long long *g_trace_counter = nullptr;
-uint32_t g_refill_lanes = kRefillLanes;
-
-int fail(int code, const char *fmt, const char *detail = "") {
-    char buf[256];
-    snprintf(buf, sizeof buf, fmt, detail);
-    g_err = buf;
-    return code;
-}
+using apt::clear_error;
+int fail(int code, const char *fmt, const char *detail = "") { return apt::set_error(code, fmt, detail); }
+int hip_fail(hipError_t e) { return fail(APT_ERR_DEVICE, "HIP: %s", hipGetErrorString(e)); }
 
 void build_leaves(uint32_t n, std::vector<std::pair<uint32_t, uint32_t>> &out) {
     if (n <= 128) { out.push_back({n, 0u}); return; }
@@ -70,13 +63,11 @@ int check_params(const apt_render_params *p) {
     return APT_OK;
 }
 
-int hip_fail(hipError_t e) { return fail(APT_ERR_DEVICE, "HIP: %s", hipGetErrorString(e)); }
-
-TraceArgs make_trace_args(const apt_render_params *p) {
+TraceArgs make_trace_args(const apt_render_params *p, const apt_context::Values &cv) {
     TraceArgs ta;
     ta.ns = p->num_spheres; ta.depth = p->depth; ta.light = p->light_index;
-    ta.eps = p->eps; ta.gain = p->gain; ta.traced = g_trace_counter;
-    ta.refill_lanes = g_refill_lanes;
+    ta.eps = p->eps; ta.gain = p->gain; ta.traced = cv.trace_counter;
+    ta.refill_lanes = cv.refill_lanes;
     ta.grid = (p->num_spheres != 8) ? reinterpret_cast<const uint32_t *>((uintptr_t)p->accel) : nullptr;
     ta.emission = (p->flags & APT_FLAG_EMISSION) ? 1u : 0u;
     ta.rr_start = (p->flags & APT_FLAG_RR) ? (p->rr_start ? p->rr_start : 3u) : 0u;
@@ -105,70 +96,9 @@ void launch_frame_g(int group, bool retire, dim3 grid, size_t lds, hipStream_t s
     else launch_frame<MODE, SC, 1>(retire, grid, lds, st, sph, fa, ta, lp);
 }
 
-} // namespace
-
-// =============================== C-ABI ======================================================
-extern "C" {
-
-int apt_abi_version(void) { return APT_ABI_VERSION; }
-const char *apt_last_error(void) { return g_err.c_str(); }
-
-int apt_device_count(void) {
-    int n = 0;
-    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
-    return n;
-}
-
-void apt_default_params(apt_render_params *p) {
-    if (!p) return;
-    memset(p, 0, sizeof *p);
-    p->struct_size = sizeof *p;
-    p->width = 16; p->height = 16; p->samples = 1; // common.h:4-6
-    p->depth = 5;                                   // render.cpp:141
-    p->num_spheres = 8; p->light_index = 7;         // common.h:10, rt_helper.h:776
-    p->eps = 1e-4f; p->gain = 12.0f;                // common.h:9, render.cpp:194
-    p->mode = APT_MODE_KERNEL;
-}
-
-int apt_set_default_params(const apt_render_params *p) {
-    int rc = check_params(p);
-    if (rc) return rc;
-    g_default = *p;
-    g_default_init = true;
-    return APT_OK;
-}
-
-int apt_selftest_sqrt(int variant, void *stream, uint64_t first_bits, uint64_t count, uint64_t *device_result2) {
-    if (!device_result2 || variant < 0 || variant > 3) return fail(APT_ERR_ARG, "apt_selftest_sqrt: bad arguments%s");
-    if (first_bits + count > (1ull << 32)) return fail(APT_ERR_ARG, "apt_selftest_sqrt: range beyond 2^32%s");
-    if (count == 0) return APT_OK;
-    hipLaunchKernelGGL(selftest_sqrt_kernel, dim3(256 * 16), dim3(kBlock), 0, (hipStream_t)stream, variant, first_bits,
-                       count, (unsigned long long *)device_result2);
-    hipError_t e = hipGetLastError();
-    return e == hipSuccess ? APT_OK : hip_fail(e);
-}
-
-int apt_selftest_div3(void *stream, uint64_t first, uint64_t count, uint64_t *device_result3) {
-    if (!device_result3) return fail(APT_ERR_ARG, "apt_selftest_div3: bad arguments%s");
-    if (count == 0) return APT_OK;
-    hipLaunchKernelGGL(selftest_div3_kernel, dim3(256 * 16), dim3(kBlock), 0, (hipStream_t)stream, first, count,
-                       (unsigned long long *)device_result3);
-    hipError_t e = hipGetLastError();
-    return e == hipSuccess ? APT_OK : hip_fail(e);
-}
-
-int apt_set_refill_lanes(uint32_t lanes) {
-    if (lanes < 1 || lanes > 64) return fail(APT_ERR_ARG, "apt_set_refill_lanes: 1..64%s");
-    g_refill_lanes = lanes;
-    return APT_OK;
-}
-
-int apt_set_trace_counter(uint64_t *device_counter) {
-    g_trace_counter = (unsigned long long *)device_counter;
-    return APT_OK;
-}
-
-int render_do_ex(const apt_render_params *p, void *stream, const float *rays, const float *spheres, float *colors) {
+// ---- the two render launches, on an explicit snapshot of a context's values -----------------
+int do_render_paths(const apt_context::Values &cv, const apt_render_params *p, void *stream, const float *rays,
+                    const float *spheres, float *colors) {
     int rc = check_params(p);
     if (rc) return rc;
     if (!rays || !spheres || !colors) return fail(APT_ERR_ARG, "rays/spheres/colors must be non-null%s");
@@ -182,7 +112,7 @@ int render_do_ex(const apt_render_params *p, void *stream, const float *rays, co
     if (blocks > 0x7fffffffull) return fail(APT_ERR_ARG, "path_count too large for one launch; shard it%s");
     hipStream_t st = (hipStream_t)stream;
     const bool ns8 = p->num_spheres == 8;
-    const TraceArgs ta = make_trace_args(p);
+    const TraceArgs ta = make_trace_args(p, cv);
     const bool retire = p->flags & APT_FLAG_RETIRE;
     const dim3 grid((unsigned)blocks);
     const int sck = ns8 ? kScene8 : (ta.grid ? kSceneGrid : kSceneTiles);
@@ -204,15 +134,8 @@ int render_do_ex(const apt_render_params *p, void *stream, const float *rays, co
     return e == hipSuccess ? APT_OK : hip_fail(e);
 }
 
-void render_do(uint32_t blockDim, void *l2ctrl, void *stream, uint8_t *rays, uint8_t *spheres, uint8_t *colors) {
-    (void)blockDim; // the reference's 8-way partition (render.cpp:9-10,24): results do not depend on it
-    (void)l2ctrl;
-    if (!g_default_init) { apt_default_params(&g_default); g_default_init = true; }
-    (void)render_do_ex(&g_default, stream, (const float *)rays, (const float *)spheres, (float *)colors);
-}
-
-int render_frame(const apt_render_params *p, void *stream, const float *spheres, uint64_t pixel_begin,
-                 uint64_t pixel_count, float *fb, uint8_t *fb_u8) {
+int do_render_frame(const apt_context::Values &cv, const apt_render_params *p, void *stream, const float *spheres,
+                    uint64_t pixel_begin, uint64_t pixel_count, float *fb, uint8_t *fb_u8) {
     int rc = check_params(p);
     if (rc) return rc;
     if (!spheres || !fb) return fail(APT_ERR_ARG, "spheres/fb must be non-null%s");
@@ -227,7 +150,7 @@ int render_frame(const apt_render_params *p, void *stream, const float *spheres,
     if (blocks > 0x7fffffffull) return fail(APT_ERR_ARG, "pixel_count too large for one launch; shard it%s");
     hipStream_t st = (hipStream_t)stream;
     const bool ns8 = p->num_spheres == 8;
-    const TraceArgs ta = make_trace_args(p);
+    const TraceArgs ta = make_trace_args(p, cv);
     FrameArgs fa;
     camera_init(fa.cam, p->width, p->height);
     fa.width = p->width; fa.height = p->height; fa.samples = p->samples; fa.seed = p->seed;
@@ -250,7 +173,277 @@ int render_frame(const apt_render_params *p, void *stream, const float *spheres,
     return e == hipSuccess ? APT_OK : hip_fail(e);
 }
 
+// contiguous near-equal split of [0,total) into `parts`: part r -> (begin, count); the first total%parts get one more
+void split_range(uint64_t total, uint64_t r, uint64_t parts, uint64_t &begin, uint64_t &count) {
+    const uint64_t base = total / parts, extra = total % parts;
+    begin = r * base + (r < extra ? r : extra);
+    count = base + (r < extra ? 1 : 0);
+}
+
+} // namespace
+
+// ---- one process, several GPUs (include/render_mi355x.h: apt_multi_*) ---------------------------
+// The frame is cut into `bands * stripes` contiguous stripes of x-major pixels; band b renders stripes
+// b, b+bands, b+2*bands, ... on its own device and stream, and every stripe is copied straight into the full
+// framebuffer on the root device with hipMemcpyPeerAsync (xGMI: each peer has its own link to the root, so the
+// copies of different bands run in parallel; no ring, no collective needed for a gather to one root).
+struct apt_multi {
+    struct Band {
+        int device = 0;
+        hipStream_t stream = nullptr;
+        hipEvent_t start = nullptr, stop = nullptr;
+        float *sph = nullptr;          // the scene table on this device
+        float *fb = nullptr;           // [3][max stripe] per stripe, stripes back to back
+        uint8_t *u8 = nullptr;
+        uint64_t pixels = 0;           // total pixels of this band
+    };
+    std::vector<Band> bands;
+    apt_render_params params;
+    uint32_t stripes = 1;
+    uint64_t max_stripe = 0;
+    int root = 0;
+};
+
+extern "C" {
+
+int apt_abi_version(void) { return APT_ABI_VERSION; }
+
+int apt_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n;
+}
+
+// ---- contexts ---------------------------------------------------------------------------------------
+apt_context *apt_context_create(void) { clear_error(); return new (std::nothrow) apt_context(); }
+void apt_context_destroy(apt_context *ctx) { clear_error(); delete ctx; }
+
+int apt_context_set_params(apt_context *ctx, const apt_render_params *p) {
+    clear_error();
+    if (!ctx) return fail(APT_ERR_ARG, "context is null%s");
+    int rc = check_params(p);
+    if (rc) return rc;
+    ctx->set_params(*p);
+    return APT_OK;
+}
+
+int apt_context_set_trace_counter(apt_context *ctx, uint64_t *device_counter) {
+    clear_error();
+    if (!ctx) return fail(APT_ERR_ARG, "context is null%s");
+    ctx->set_trace_counter((unsigned long long *)device_counter);
+    return APT_OK;
+}
+
+int apt_context_set_refill_lanes(apt_context *ctx, uint32_t lanes) {
+    clear_error();
+    if (!ctx) return fail(APT_ERR_ARG, "context is null%s");
+    if (lanes < 1 || lanes > 64) return fail(APT_ERR_ARG, "refill lanes: 1..64%s");
+    ctx->set_refill_lanes(lanes);
+    return APT_OK;
+}
+
+void apt_context_render_do(apt_context *ctx, uint32_t blockDim, void *l2ctrl, void *stream, uint8_t *rays,
+                           uint8_t *spheres, uint8_t *colors) {
+    clear_error();
+    (void)blockDim; // the reference's 8-way partition (render.cpp:9-10,24): results do not depend on it
+    (void)l2ctrl;
+    if (!ctx) { (void)fail(APT_ERR_ARG, "context is null%s"); return; }
+    const apt_context::Values cv = ctx->snapshot();
+    (void)do_render_paths(cv, &cv.params, stream, (const float *)rays, (const float *)spheres, (float *)colors);
+}
+
+int apt_context_render_do_ex(apt_context *ctx, const apt_render_params *p, void *stream, const float *rays,
+                             const float *spheres, float *colors) {
+    clear_error();
+    if (!ctx) return fail(APT_ERR_ARG, "context is null%s");
+    return do_render_paths(ctx->snapshot(), p, stream, rays, spheres, colors);
+}
+
+int apt_context_render_frame(apt_context *ctx, const apt_render_params *p, void *stream, const float *spheres,
+                             uint64_t pixel_begin, uint64_t pixel_count, float *fb, uint8_t *fb_u8) {
+    clear_error();
+    if (!ctx) return fail(APT_ERR_ARG, "context is null%s");
+    return do_render_frame(ctx->snapshot(), p, stream, spheres, pixel_begin, pixel_count, fb, fb_u8);
+}
+
+// ---- the context-free forms: the process-wide default context -----------------------------------------
+int apt_set_default_params(const apt_render_params *p) { return apt_context_set_params(&apt::default_context(), p); }
+int apt_set_refill_lanes(uint32_t lanes) { return apt_context_set_refill_lanes(&apt::default_context(), lanes); }
+int apt_set_trace_counter(uint64_t *device_counter) { return apt_context_set_trace_counter(&apt::default_context(), device_counter); }
+
+int render_do_ex(const apt_render_params *p, void *stream, const float *rays, const float *spheres, float *colors) {
+    return apt_context_render_do_ex(&apt::default_context(), p, stream, rays, spheres, colors);
+}
+
+void render_do(uint32_t blockDim, void *l2ctrl, void *stream, uint8_t *rays, uint8_t *spheres, uint8_t *colors) {
+    apt_context_render_do(&apt::default_context(), blockDim, l2ctrl, stream, rays, spheres, colors);
+}
+
+// The same function under a name a C++ translation unit can bind next to its own C++-linkage render_do
+// (render_do_cxx.cpp: the reference declares render_do WITHOUT extern "C", src/main.cpp:9-10).
+void apt_render_do(uint32_t blockDim, void *l2ctrl, void *stream, uint8_t *rays, uint8_t *spheres, uint8_t *colors) {
+    apt_context_render_do(&apt::default_context(), blockDim, l2ctrl, stream, rays, spheres, colors);
+}
+
+int render_frame(const apt_render_params *p, void *stream, const float *spheres, uint64_t pixel_begin,
+                 uint64_t pixel_count, float *fb, uint8_t *fb_u8) {
+    return apt_context_render_frame(&apt::default_context(), p, stream, spheres, pixel_begin, pixel_count, fb, fb_u8);
+}
+
+// The CPU-simulator shape of the boundary (src/main.cpp:21-44: ICPU_RUN_KF(render, blockDim, rays, spheres,
+// colors) on HOST buffers, synchronous): copies in, renders with the default context's parameters, copies out.
+int apt_render_host(uint32_t blockDim, const uint8_t *rays, const uint8_t *spheres, uint8_t *colors) {
+    clear_error();
+    if (!rays || !spheres || !colors) return fail(APT_ERR_ARG, "rays/spheres/colors must be non-null%s");
+    const apt_context::Values cv = apt::default_context().snapshot();
+    const apt_render_params &p = cv.params;
+    const size_t n = (size_t)p.width * p.height * 4u * p.samples;
+    const size_t sph_bytes = ((size_t)p.num_spheres * 10 + 127) / 128 * 128 * sizeof(float);
+    float *d_rays = nullptr, *d_sph = nullptr, *d_col = nullptr;
+    hipError_t e = hipMalloc(&d_rays, n * 24);
+    if (e == hipSuccess) e = hipMalloc(&d_sph, sph_bytes);
+    if (e == hipSuccess) e = hipMalloc(&d_col, n * 12);
+    if (e == hipSuccess) e = hipMemcpy(d_rays, rays, n * 24, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_sph, spheres, sph_bytes, hipMemcpyHostToDevice);
+    int rc = APT_OK;
+    if (e == hipSuccess) {
+        (void)blockDim;
+        rc = do_render_paths(cv, &p, nullptr, d_rays, d_sph, d_col);
+        if (rc == APT_OK) e = hipMemcpy(colors, d_col, n * 12, hipMemcpyDeviceToHost); // synchronises the null stream
+    }
+    (void)hipFree(d_rays); (void)hipFree(d_sph); (void)hipFree(d_col);
+    if (rc != APT_OK) return rc;
+    return e == hipSuccess ? APT_OK : hip_fail(e);
+}
+
+// ---- one process, several GPUs ---------------------------------------------------------------------------
+void apt_multi_destroy(apt_multi *m) {
+    clear_error();
+    if (!m) return;
+    for (auto &b : m->bands) {
+        if (hipSetDevice(b.device) != hipSuccess) continue;
+        if (b.start) (void)hipEventDestroy(b.start);
+        if (b.stop) (void)hipEventDestroy(b.stop);
+        if (b.stream) (void)hipStreamDestroy(b.stream);
+        (void)hipFree(b.sph); (void)hipFree(b.fb); (void)hipFree(b.u8);
+    }
+    (void)hipSetDevice(m->root);
+    delete m;
+}
+
+int apt_multi_create(const int *device_ids, uint32_t num_bands, uint32_t stripes, const apt_render_params *p,
+                     const float *spheres_host, apt_multi **out) {
+    clear_error();
+    if (!device_ids || !num_bands || !stripes || !spheres_host || !out) return fail(APT_ERR_ARG, "apt_multi_create: bad arguments%s");
+    int rc = check_params(p);
+    if (rc) return rc;
+    if (p->accel) return fail(APT_ERR_ARG, "apt_multi_create: accel is a single-device address; not supported here%s");
+    const int ndev = apt_device_count();
+    for (uint32_t b = 0; b < num_bands; ++b)
+        if (device_ids[b] < 0 || device_ids[b] >= ndev) return fail(APT_ERR_DEVICE, "apt_multi_create: device id out of range%s");
+    const uint64_t npix = (uint64_t)p->width * p->height, parts = (uint64_t)num_bands * stripes;
+    if (parts > npix) return fail(APT_ERR_ARG, "apt_multi_create: more stripes than pixels%s");
+    apt_multi *m = new (std::nothrow) apt_multi();
+    if (!m) return fail(APT_ERR_DEVICE, "out of host memory%s");
+    m->params = *p; m->stripes = stripes; m->root = device_ids[0];
+    uint64_t b0, c0;
+    split_range(npix, 0, parts, b0, c0);
+    m->max_stripe = c0;
+    m->bands.resize(num_bands);
+    const size_t sph_bytes = ((size_t)p->num_spheres * 10 + 127) / 128 * 128 * sizeof(float);
+    hipError_t e = hipSuccess;
+    for (uint32_t b = 0; b < num_bands && e == hipSuccess; ++b) {
+        apt_multi::Band &bd = m->bands[b];
+        bd.device = device_ids[b];
+        e = hipSetDevice(bd.device);
+        if (e == hipSuccess && bd.device != m->root) { // let the root's copy engine read this device (no-op if already on)
+            int can = 0;
+            (void)hipDeviceCanAccessPeer(&can, bd.device, m->root);
+            if (can) { hipError_t pe = hipDeviceEnablePeerAccess(m->root, 0); if (pe != hipSuccess) (void)hipGetLastError(); }
+        }
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&bd.stream, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreate(&bd.start);
+        if (e == hipSuccess) e = hipEventCreate(&bd.stop);
+        if (e == hipSuccess) e = hipMalloc(&bd.sph, sph_bytes);
+        if (e == hipSuccess) e = hipMemcpy(bd.sph, spheres_host, sph_bytes, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMalloc(&bd.fb, (size_t)stripes * 3 * m->max_stripe * sizeof(float));
+        if (e == hipSuccess) e = hipMalloc(&bd.u8, (size_t)stripes * 3 * m->max_stripe);
+    }
+    (void)hipSetDevice(m->root);
+    if (e != hipSuccess) { rc = hip_fail(e); apt_multi_destroy(m); apt::set_error(rc, "apt_multi_create: HIP: %s", hipGetErrorString(e)); return rc; }
+    *out = m;
+    return APT_OK;
+}
+
+int apt_multi_render(apt_multi *m, float *fb_root, uint8_t *u8_root, float *band_kernel_ms) {
+    clear_error();
+    if (!m || !fb_root) return fail(APT_ERR_ARG, "apt_multi_render: handle/fb must be non-null%s");
+    const apt_context::Values cv = apt::default_context().snapshot();
+    const uint64_t npix = (uint64_t)m->params.width * m->params.height;
+    const uint64_t nb = m->bands.size(), parts = nb * m->stripes;
+    int rc = APT_OK;
+    hipError_t e = hipSuccess;
+    for (uint64_t b = 0; b < nb && rc == APT_OK && e == hipSuccess; ++b) {
+        apt_multi::Band &bd = m->bands[b];
+        e = hipSetDevice(bd.device);
+        if (e == hipSuccess) e = hipEventRecord(bd.start, bd.stream);
+        for (uint32_t s = 0; s < m->stripes && rc == APT_OK && e == hipSuccess; ++s) {
+            uint64_t begin, count;
+            split_range(npix, (uint64_t)s * nb + b, parts, begin, count);   // interleaved: stripe s*nb + b belongs to band b
+            float *fb = bd.fb + (size_t)s * 3 * m->max_stripe;
+            uint8_t *u8 = bd.u8 + (size_t)s * 3 * m->max_stripe;
+            rc = do_render_frame(cv, &m->params, bd.stream, bd.sph, begin, count, fb, u8_root ? u8 : nullptr);
+            if (rc != APT_OK) break;
+            if (s + 1 == m->stripes) e = hipEventRecord(bd.stop, bd.stream);  // kernels only: the copies follow
+        }
+        for (uint32_t s = 0; s < m->stripes && rc == APT_OK && e == hipSuccess; ++s) {
+            uint64_t begin, count;
+            split_range(npix, (uint64_t)s * nb + b, parts, begin, count);
+            const float *fb = bd.fb + (size_t)s * 3 * m->max_stripe;
+            const uint8_t *u8 = bd.u8 + (size_t)s * 3 * m->max_stripe;
+            for (int ch = 0; ch < 3 && e == hipSuccess; ++ch)   // band-local planes [3][count] -> planes of the full frame
+                e = hipMemcpyPeerAsync(fb_root + (size_t)ch * npix + begin, m->root, fb + (size_t)ch * count, bd.device,
+                                       count * sizeof(float), bd.stream);
+            if (u8_root && e == hipSuccess)
+                e = hipMemcpyPeerAsync(u8_root + begin * 3, m->root, u8, bd.device, count * 3, bd.stream);
+        }
+    }
+    for (auto &bd : m->bands) { // wait for every band (also after an error: nothing may still be writing)
+        if (hipSetDevice(bd.device) == hipSuccess) { hipError_t se = hipStreamSynchronize(bd.stream); if (e == hipSuccess) e = se; }
+    }
+    if (band_kernel_ms && rc == APT_OK && e == hipSuccess)
+        for (uint64_t b = 0; b < nb; ++b) {
+            (void)hipSetDevice(m->bands[b].device);
+            if (hipEventElapsedTime(&band_kernel_ms[b], m->bands[b].start, m->bands[b].stop) != hipSuccess) band_kernel_ms[b] = -1.0f;
+        }
+    (void)hipSetDevice(m->root);
+    if (rc != APT_OK) return rc;
+    return e == hipSuccess ? APT_OK : hip_fail(e);
+}
+
+int apt_selftest_sqrt(int variant, void *stream, uint64_t first_bits, uint64_t count, uint64_t *device_result2) {
+    clear_error();
+    if (!device_result2 || variant < 0 || variant > 3) return fail(APT_ERR_ARG, "apt_selftest_sqrt: bad arguments%s");
+    if (first_bits + count > (1ull << 32)) return fail(APT_ERR_ARG, "apt_selftest_sqrt: range beyond 2^32%s");
+    if (count == 0) return APT_OK;
+    hipLaunchKernelGGL(selftest_sqrt_kernel, dim3(256 * 16), dim3(kBlock), 0, (hipStream_t)stream, variant, first_bits,
+                       count, (unsigned long long *)device_result2);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? APT_OK : hip_fail(e);
+}
+
+int apt_selftest_div3(void *stream, uint64_t first, uint64_t count, uint64_t *device_result3) {
+    clear_error();
+    if (!device_result3) return fail(APT_ERR_ARG, "apt_selftest_div3: bad arguments%s");
+    if (count == 0) return APT_OK;
+    hipLaunchKernelGGL(selftest_div3_kernel, dim3(256 * 16), dim3(kBlock), 0, (hipStream_t)stream, first, count,
+                       (unsigned long long *)device_result3);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? APT_OK : hip_fail(e);
+}
+
 int apt_test_scene(const apt_render_params *p, void *stream, const float *rays, const float *spheres, float *out) {
+    clear_error();
     int rc = check_params(p);
     if (rc) return rc;
     if (!rays || !spheres || !out) return fail(APT_ERR_ARG, "rays/spheres/out must be non-null%s");
@@ -264,6 +457,7 @@ int apt_test_scene(const apt_render_params *p, void *stream, const float *rays, 
 }
 
 int apt_gen_rays_device(const apt_render_params *p, void *stream, float *rays) {
+    clear_error();
     int rc = check_params(p);
     if (rc) return rc;
     if (!rays) return fail(APT_ERR_ARG, "rays must be non-null%s");
@@ -285,6 +479,7 @@ int apt_gen_rays_device(const apt_render_params *p, void *stream, float *rays) {
 
 int apt_gen_rays_mt_device(const apt_render_params *p, void *stream, const uint32_t *checkpoints, uint32_t stride,
                            uint64_t num_checkpoints, float *rays) {
+    clear_error();
     int rc = check_params(p);
     if (rc) return rc;
     if (!rays || !checkpoints || stride == 0) return fail(APT_ERR_ARG, "rays/checkpoints must be non-null, stride > 0%s");
@@ -307,6 +502,7 @@ int apt_gen_rays_mt_device(const apt_render_params *p, void *stream, const uint3
 }
 
 int apt_decode_color_device(const apt_render_params *p, void *stream, const float *colors, float *fb, uint8_t *fb_u8) {
+    clear_error();
     int rc = check_params(p);
     if (rc) return rc;
     if (!colors || !fb) return fail(APT_ERR_ARG, "colors/fb must be non-null%s");

@@ -36,9 +36,116 @@ def render_do(blockDim, l2ctrl, stream, rays, spheres, colors):
     require_gpu()
     lib().render_do(ctypes.c_uint32(blockDim), None, _stream_handle(stream), _dev_f32(rays, "rays"),
                     _dev_f32(spheres, "spheres"), _dev_f32(colors, "colors"))
-    err = lib().apt_last_error()
-    if err:
-        raise _lib.AptError("render_do: " + err.decode())
+    check(lib().apt_last_status(), "render_do")   # void like the reference: the outcome of THIS call, on this thread
+
+
+class Context:
+    """apt_context: private settings for render_do / render_do_ex / render_frame (instead of the process-wide
+    default context); safe to use from several threads, one context per thread needs no coordination at all."""
+
+    def __init__(self, params=None):
+        self._h = ctypes.c_void_p(lib().apt_context_create())
+        if not self._h:
+            raise _lib.AptError("apt_context_create failed")
+        if params is not None:
+            self.set_params(params)
+
+    def close(self):
+        if self._h:
+            lib().apt_context_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def set_params(self, params):
+        check(lib().apt_context_set_params(self._h, ctypes.byref(params)), "apt_context_set_params")
+
+    def set_refill_lanes(self, lanes):
+        check(lib().apt_context_set_refill_lanes(self._h, ctypes.c_uint32(lanes)), "apt_context_set_refill_lanes")
+
+    def set_trace_counter(self, tensor_or_none):
+        ptr = ctypes.c_void_p(tensor_or_none.data_ptr()) if tensor_or_none is not None else None
+        check(lib().apt_context_set_trace_counter(self._h, ptr), "apt_context_set_trace_counter")
+
+    def render_do(self, blockDim, l2ctrl, stream, rays, spheres, colors):
+        require_gpu()
+        lib().apt_context_render_do(self._h, ctypes.c_uint32(blockDim), None, _stream_handle(stream), _dev_f32(rays, "rays"),
+                                    _dev_f32(spheres, "spheres"), _dev_f32(colors, "colors"))
+        check(lib().apt_last_status(), "apt_context_render_do")
+
+    def render_do_ex(self, params, stream, rays, spheres, colors):
+        require_gpu()
+        n = params.num_paths
+        check(lib().apt_context_render_do_ex(self._h, ctypes.byref(params), _stream_handle(stream), _dev_f32(rays, "rays", 6 * n),
+                                             _dev_f32(spheres, "spheres", sphere_floats(params.num_spheres)),
+                                             _dev_f32(colors, "colors", 3 * n)), "apt_context_render_do_ex")
+
+    def render_frame(self, params, spheres, pixel_begin=0, pixel_count=None, stream=None, fb=None, fb_u8=None):
+        require_gpu()
+        npix = params.width * params.height
+        if pixel_count is None:
+            pixel_count = npix - pixel_begin
+        if fb is None:
+            fb = torch.empty((3, pixel_count), dtype=torch.float32, device=spheres.device)
+        if fb_u8 is None:
+            fb_u8 = torch.empty((pixel_count, 3), dtype=torch.uint8, device=spheres.device)
+        check(lib().apt_context_render_frame(self._h, ctypes.byref(params), _stream_handle(stream),
+                                             _dev_f32(spheres, "spheres", sphere_floats(params.num_spheres)),
+                                             ctypes.c_uint64(pixel_begin), ctypes.c_uint64(pixel_count),
+                                             _dev_f32(fb, "fb", 3 * pixel_count), ctypes.c_void_p(fb_u8.data_ptr())),
+              "apt_context_render_frame")
+        return fb, fb_u8
+
+
+def render_host(blockDim, rays, spheres, colors):
+    """The CPU-simulator shape of the boundary (src/main.cpp:21-44, ICPU_RUN_KF(render, ...)): HOST numpy float32
+    buffers in, colours out, synchronous.  Uses the default context's parameters (set_default_params)."""
+    import numpy as np
+    require_gpu()
+    for a, name in ((rays, "rays"), (spheres, "spheres"), (colors, "colors")):
+        if not (isinstance(a, np.ndarray) and a.dtype == np.float32 and a.flags.c_contiguous):
+            raise _lib.AptError(f"{name} must be a C-contiguous float32 numpy array")
+    check(lib().apt_render_host(ctypes.c_uint32(blockDim), ctypes.c_void_p(rays.ctypes.data),
+                                ctypes.c_void_p(spheres.ctypes.data), ctypes.c_void_p(colors.ctypes.data)), "apt_render_host")
+
+
+class MultiGpu:
+    """apt_multi: one process, several GPUs.  Band b of the frame renders on device_ids[b]; with stripes > 1 the
+    bands are interleaved stripes.  The frame is assembled on device_ids[0] by peer copies (no collective)."""
+
+    def __init__(self, params, spheres_host, device_ids, stripes=1):
+        import numpy as np
+        require_gpu()
+        sph = np.ascontiguousarray(spheres_host, dtype=np.float32)
+        if sph.size != sphere_floats(params.num_spheres):
+            raise _lib.AptError("spheres_host has the wrong length")
+        ids = (ctypes.c_int * len(device_ids))(*device_ids)
+        self._h = ctypes.c_void_p()
+        check(lib().apt_multi_create(ids, ctypes.c_uint32(len(device_ids)), ctypes.c_uint32(stripes), ctypes.byref(params),
+                                     ctypes.c_void_p(sph.ctypes.data), ctypes.byref(self._h)), "apt_multi_create")
+        self.params, self.device_ids, self.stripes = params, list(device_ids), stripes
+        self.band_kernel_ms = [0.0] * len(device_ids)
+
+    def render(self, fb=None, fb_u8=None):
+        """-> (fb [3][W*H] float32, u8 [W*H][3]) on device_ids[0]; synchronous."""
+        npix = self.params.width * self.params.height
+        dev = torch.device("cuda", self.device_ids[0])
+        if fb is None:
+            fb = torch.empty((3, npix), dtype=torch.float32, device=dev)
+        if fb_u8 is None:
+            fb_u8 = torch.empty((npix, 3), dtype=torch.uint8, device=dev)
+        ms = (ctypes.c_float * len(self.device_ids))()
+        check(lib().apt_multi_render(self._h, ctypes.c_void_p(fb.data_ptr()), ctypes.c_void_p(fb_u8.data_ptr()), ms),
+              "apt_multi_render")
+        self.band_kernel_ms = list(ms)
+        return fb, fb_u8
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().apt_multi_destroy(self._h)
+            self._h = None
+
+    __del__ = close
 
 
 def set_default_params(params):

@@ -9,7 +9,17 @@
  * sizes only; no C++ or torch types.  All device entry points ENQUEUE work on the HIP
  * stream they are given and return without synchronising (the caller synchronises, as
  * src/main.cpp:75 does with aclrtSynchronizeStream); they never allocate, free or retain
- * memory, so they are legal inside a hipGraph capture.
+ * memory, so they are legal inside a hipGraph capture.  (The exceptions say so: apt_render_host and
+ * apt_multi_* are synchronous conveniences that own device buffers.)
+ *
+ * Thread safety.  apt_last_error() / apt_last_status() are PER THREAD and describe the last call made on
+ * that thread: every entry point clears the record on entry and sets it on failure.  The settings the
+ * reference keeps as compile-time constants live in an apt_context; its setters and the snapshot a render
+ * call takes are serialised inside the context, so concurrent calls on one context are safe and each call
+ * sees one consistent set of values; different contexts share nothing.  The context-free forms
+ * (render_do, apt_set_default_params, apt_set_trace_counter, apt_set_refill_lanes) act on one process-wide
+ * default context with the same guarantees -- two threads that want DIFFERENT render_do parameters use two
+ * contexts.
  *
  * Buffers (little-endian IEEE float32):
  *   rays     [6][N]   planes ox,oy,oz,dx,dy,dz              scripts/gen_data.py:65-71
@@ -29,10 +39,10 @@
 extern "C" {
 #endif
 
-#define APT_ABI_VERSION 1
+#define APT_ABI_VERSION 2
 
 /* status codes returned by the *_ex / frame entry points (render_do itself is void,
- * like the reference, and reports through apt_last_error()). */
+ * like the reference, and reports through apt_last_status() / apt_last_error()). */
 enum {
     APT_OK = 0,
     APT_ERR_ARG = 1,       /* null pointer, zero size, size not representable            */
@@ -110,8 +120,39 @@ void apt_default_params(apt_render_params *p);
 void render_do(uint32_t blockDim, void *l2ctrl, void *stream,
                uint8_t *rays, uint8_t *spheres, uint8_t *colors);
 
-/* The parameters render_do() uses (process-wide).  Returns APT_OK or APT_ERR_*. */
+/* The same entry under a second name.  The reference declares render_do with C++ linkage
+ * (`extern void render_do(...)` without extern "C", src/main.cpp:9-10), so an UNMODIFIED main.o references
+ * the mangled symbol _Z9render_dojPvS_PhS0_S0_: the library exports that symbol as well (render_do_cxx.cpp,
+ * which forwards here), and a translation unit holding the reference's declaration verbatim links against
+ * librender_mi355x.so as it is (tests/test_host_abi.py builds one). */
+void apt_render_do(uint32_t blockDim, void *l2ctrl, void *stream,
+                   uint8_t *rays, uint8_t *spheres, uint8_t *colors);
+
+/* The parameters render_do() uses (the process-wide default context).  Returns APT_OK or APT_ERR_*. */
 int apt_set_default_params(const apt_render_params *p);
+
+/* The CPU-simulator shape of the boundary: src/main.cpp:21-44 calls ICPU_RUN_KF(render, blockDim, rays,
+ * spheres, colors) on HOST buffers and the call is synchronous.  This entry takes the same HOST buffers
+ * (24*N, 512 (padded table) and 12*N bytes for the default context's parameters), copies them to device 0's
+ * current device, renders, copies the colours back and returns when they are there.  Allocates and frees its
+ * device buffers; not capture-safe.  (The arithmetic still runs on the GPU: there is no CPU path.) */
+int apt_render_host(uint32_t blockDim, const uint8_t *rays, const uint8_t *spheres, uint8_t *colors);
+
+/* ---- contexts: per-caller settings instead of process-wide ones ---------------------------------
+ * A context holds what the reference fixes at compile time (the parameters its render_do renders with) and
+ * the diagnostics knobs below.  See "Thread safety" at the top. */
+typedef struct apt_context apt_context;
+apt_context *apt_context_create(void);                 /* reference defaults; NULL when out of memory */
+void apt_context_destroy(apt_context *ctx);
+int  apt_context_set_params(apt_context *ctx, const apt_render_params *p);
+int  apt_context_set_trace_counter(apt_context *ctx, uint64_t *device_counter);
+int  apt_context_set_refill_lanes(apt_context *ctx, uint32_t lanes);
+void apt_context_render_do(apt_context *ctx, uint32_t blockDim, void *l2ctrl, void *stream,
+                           uint8_t *rays, uint8_t *spheres, uint8_t *colors);
+int  apt_context_render_do_ex(apt_context *ctx, const apt_render_params *p, void *stream,
+                              const float *rays, const float *spheres, float *colors);
+int  apt_context_render_frame(apt_context *ctx, const apt_render_params *p, void *stream, const float *spheres,
+                              uint64_t pixel_begin, uint64_t pixel_count, float *fb, uint8_t *fb_u8);
 
 /* Extended form of the same boundary with run-time parameters.
  * rays/colors are the FULL [6][N] / [3][N] device buffers; the call reads and writes only
@@ -133,6 +174,26 @@ int render_do_ex(const apt_render_params *p, void *stream,
  * p->path_begin/path_count are ignored here. */
 int render_frame(const apt_render_params *p, void *stream, const float *spheres,
                  uint64_t pixel_begin, uint64_t pixel_count, float *fb, uint8_t *fb_u8);
+
+/* ---- one process, several GPUs (the reference's 8-block split, src/render.cpp:9-10,24-27, across devices) ----
+ * The frame's x-major pixel range is cut into num_bands*stripes contiguous stripes; band b renders stripes
+ * b, b+num_bands, ... (stripes == 1: one contiguous band per device, the reference's split; stripes > 1
+ * interleaves them, which balances APT_FLAG_RETIRE's uneven columns) on device_ids[b] with render_frame on a
+ * stream of its own, and every stripe is copied straight into the full frame on the root device
+ * (device_ids[0]) with hipMemcpyPeerAsync -- over xGMI each peer has its own link to the root, so the copies
+ * of different bands run in parallel; a gather to one root needs no collective.  A device may appear more
+ * than once in device_ids (several bands on one GPU).
+ *   apt_multi_create   allocates per-band streams, the scene copy and stripe buffers (spheres_host: HOST table)
+ *   apt_multi_render   renders one frame into fb_root [3][W*H] (+ u8_root [W*H][3] or NULL), DEVICE pointers on
+ *                      the root device; synchronous (returns when the frame is complete);
+ *                      band_kernel_ms: optional HOST float[num_bands], each band's kernel time (HIP events)
+ * apt_render_params.accel is refused (a grid address belongs to one device).  One process per GPU with
+ * torch.distributed (ascendpathtracing_amd/dist.py) is the other, equivalent way to shard. */
+typedef struct apt_multi apt_multi;
+int  apt_multi_create(const int *device_ids, uint32_t num_bands, uint32_t stripes, const apt_render_params *p,
+                      const float *spheres_host, apt_multi **out);
+int  apt_multi_render(apt_multi *m, float *fb_root, uint8_t *u8_root, float *band_kernel_ms);
+void apt_multi_destroy(apt_multi *m);
 
 /* First-hit debug mode, scripts/gen_data.py:134-188 test_scene: out [3][N] = emission of the
  * light sphere when it is the nearest hit, the hit sphere's colour otherwise, 0 on a miss
@@ -214,11 +275,13 @@ int apt_selftest_div3(void *stream, uint64_t first, uint64_t count, uint64_t *de
 
 /* Tuning knob of the APT_FLAG_RETIRE compaction in render_frame: a wave runs its (expensive,
  * float64) ray-generate when at least `lanes` of its 64 lanes have an empty ray slot (default
- * 32).  Speed only: results are bit-identical for every value.  Process-wide. */
+ * 32).  Speed only: results are bit-identical for every value.  Default context. */
 int apt_set_refill_lanes(uint32_t lanes);
 
 int         apt_abi_version(void);
-const char *apt_last_error(void);       /* thread-local, "" when none */
+const char *apt_last_error(void);       /* this thread's last call: "" when it succeeded */
+int         apt_last_status(void);      /* this thread's last call: APT_OK or APT_ERR_* (how a caller of the void
+                                           render_do learns the outcome) */
 int         apt_device_count(void);     /* number of HIP devices, 0 when none */
 
 #ifdef __cplusplus

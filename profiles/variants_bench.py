@@ -1,0 +1,80 @@
+#!/usr/bin/env python3
+"""A/B timing of builds of librender_mi355x.so on one MI355X (run through gpurun):
+
+    python profiles/variants_bench.py name=path/to/lib.so [name=path ...] [--reps 7]
+
+Per library, in a child process (one HIP runtime image each), through raw ctypes on the entry points every
+build has (apt_default_params, render_frame): the C2 frame (1920x1080, S=64, depth 8, K-mode, no flags) timed
+with HIP events via torch, the same at depth 0 (ray-generate + accumulation only), with APT_FLAG_RETIRE, and the
+frame's chunk hashes against tests/golden/fullsize_hashes.json (oracle-made).  One JSON line per library."""
+import argparse, ctypes, hashlib, json, os, subprocess, sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def child(name, path, reps):
+    import numpy as np
+    import torch
+    sys.path.insert(0, ROOT)
+    from ascendpathtracing_amd._lib import RenderParams
+    lib = ctypes.CDLL(path)
+    lib.apt_default_params.restype = None
+    lib.apt_last_error.restype = ctypes.c_char_p
+    sph_h = np.zeros(128, dtype=np.float32)
+    assert lib.apt_gen_spheres_host(sph_h.ctypes.data_as(ctypes.c_void_p)) == 0
+    sph = torch.from_numpy(sph_h).cuda()
+    W, H, S = 1920, 1080, 64
+    npix = W * H
+    fb = torch.empty((3, npix), dtype=torch.float32, device="cuda")
+    u8 = torch.empty((npix, 3), dtype=torch.uint8, device="cuda")
+
+    def params(depth, flags=0, mode=0):
+        p = RenderParams()
+        lib.apt_default_params(ctypes.byref(p))
+        p.width, p.height, p.samples, p.depth, p.flags, p.mode, p.seed = W, H, S, depth, flags, mode, 0
+        return p
+
+    def run(p):
+        rc = lib.render_frame(ctypes.byref(p), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream), ctypes.c_void_p(sph.data_ptr()),
+                              ctypes.c_uint64(0), ctypes.c_uint64(npix), ctypes.c_void_p(fb.data_ptr()), ctypes.c_void_p(u8.data_ptr()))
+        assert rc == 0, lib.apt_last_error()
+
+    def timeit(p):
+        run(p); run(p); torch.cuda.synchronize()
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+        for a, b in ev:
+            a.record(); run(p); b.record()
+        torch.cuda.synchronize()
+        t = sorted(a.elapsed_time(b) for a, b in ev)
+        return round(t[0], 3), round(t[len(t) // 2], 3)
+
+    out = {"lib": name}
+    out["c2_ms_min_med"] = timeit(params(8))
+    with open(os.path.join(ROOT, "tests", "golden", "fullsize_hashes.json")) as f:
+        case = json.load(f)["cases"]["C2"]
+    run(params(8)); torch.cuda.synchronize()
+    fbh, u8h = fb.cpu().numpy(), u8.cpu().numpy()
+    ok = all(hashlib.sha256(np.ascontiguousarray(fbh[:, b:b + c]).tobytes()).hexdigest() == case["fb_sha256"][k] and
+             hashlib.sha256(np.ascontiguousarray(u8h[b:b + c]).tobytes()).hexdigest() == case["u8_sha256"][k]
+             for k, (b, c) in enumerate(case["ranges"]))
+    out["c2_frame_equals_oracle"] = bool(ok)
+    out["depth0_ms_min_med"] = timeit(params(0))
+    out["c2_retire_ms_min_med"] = timeit(params(8, flags=1))
+    out["c2_omode_ms_min_med"] = timeit(params(8, mode=1))
+    out["c5_d32_ms_min_med"] = timeit(params(32))
+    print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "--child":
+        child(sys.argv[2], sys.argv[3], int(sys.argv[4]))
+        sys.exit(0)
+    ap = argparse.ArgumentParser()
+    ap.add_argument("libs", nargs="+")
+    ap.add_argument("--reps", type=int, default=7)
+    a = ap.parse_args()
+    for spec in a.libs:
+        name, path = spec.split("=", 1)
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", name, os.path.abspath(path), str(a.reps)])
+        if r.returncode:
+            print(json.dumps({"lib": name, "error": r.returncode}), flush=True)

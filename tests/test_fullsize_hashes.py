@@ -1,0 +1,163 @@
+"""Every BASELINE.json configuration at its FULL size on the HIP path, compared by SHA-256 with the frames the
+oracle produced in the build container (tests/golden/fullsize_hashes.json, written by
+tests/golden/make_fullsize_hashes.py).  Always on under -m gpu: the whole file costs ~2 s of GPU time.
+
+    C2        1920x1080, 256 spp, 8 bounces, demo scene           whole frame, K-mode (+ O-mode ranges)
+    C5_rr     1920x1080, 256 spp, 32 bounces, Russian roulette    whole frame (BASELINE configs[4] as named)
+    C5_full   the same without roulette                           whole frame
+    C3_bands  4096x4096, 1024 spp, 8 bounces                      first/last column of each of the 8 rank bands
+    C4_*      10 000-sphere scene                                 a whole 480x270 frame (brute force and grid) and
+                                                                  ranges of the 1080p / 256 spp frame (grid)
+The CPU test at the bottom re-runs the oracle on a few ranges so that the committed file cannot drift from it.
+"""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+with open(os.path.join(ROOT, "tests", "golden", "fullsize_hashes.json")) as _f:
+    HASHES = json.load(_f)["cases"]
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+@pytest.fixture(scope="module")
+def apt():
+    import __graft_entry__ as g
+    g.build()
+    import ascendpathtracing_amd as pkg
+    from ascendpathtracing_amd import _lib, gen_data, render
+    _lib.require_gpu()          # fail loudly: no silent fallback
+    pkg.render, pkg.gen_data = render, gen_data
+    return pkg
+
+
+def _scene(apt, case, torch):
+    """-> (device scene table, num_spheres, device grid or None)"""
+    if case["scene"] == "demo":
+        return torch.from_numpy(apt.gen_data.gen_spheres()).cuda(), 8, None
+    ns, seed = case["scene"]["num_spheres"], case["scene"]["seed"]
+    host = apt.gen_data.gen_scene(ns, seed=seed)
+    grid = torch.from_numpy(apt.gen_data.build_grid(host, ns).view(np.int32)).cuda()
+    return torch.from_numpy(host).cuda(), ns, grid
+
+
+def _params(apt, case, ns, flags=None, accel=0):
+    return apt.make_params(case["w"], case["h"], case["s"], depth=case["depth"], num_spheres=ns,
+                           mode=apt.APT_MODE_ORACLE if case["mode"] == "O" else apt.APT_MODE_KERNEL,
+                           flags=case["flags"] if flags is None else flags, seed=case["seed"],
+                           rr_start=case.get("rr_start", 0), accel=accel)
+
+
+def _check_ranges(case, fb, u8, base, what):
+    """fb [3][n] / u8 [n][3] device tensors holding pixels [base, base+n); compares every range inside."""
+    fb, u8 = fb.cpu().numpy(), u8.cpu().numpy()
+    n, bad = fb.shape[1], []
+    for k, (b, c) in enumerate(case["ranges"]):
+        if b < base or b + c > base + n:
+            continue
+        if sha(fb[:, b - base:b - base + c]) != case["fb_sha256"][k] or sha(u8[b - base:b - base + c]) != case["u8_sha256"][k]:
+            bad.append(k)
+    assert not bad, f"{what}: ranges {bad} differ from the oracle's frame"
+
+
+def _whole_frame(apt, name, flag_sets):
+    import torch
+    case = HASHES[name]
+    sph, ns, _ = _scene(apt, case, torch)
+    assert sum(c for _, c in case["ranges"]) == case["w"] * case["h"]       # the ranges tile the frame
+    for flags in flag_sets:
+        fb, u8 = apt.render.render_frame(_params(apt, case, ns, flags=flags), sph)
+        torch.cuda.synchronize()
+        _check_ranges(case, fb, u8, 0, f"{name} flags={flags}")
+
+
+@pytest.mark.gpu
+def test_c2_whole_frame_k_mode(apt):
+    """BASELINE configs[1], all 2 073 600 pixels / 4.25 G segments: the benchmarked kernel (no flags) and its
+    compaction variant (APT_FLAG_RETIRE, result preserving)."""
+    _whole_frame(apt, "C2", [0, apt.APT_FLAG_RETIRE])
+
+
+@pytest.mark.gpu
+def test_c2_o_mode_ranges(apt):
+    import torch
+    case = HASHES["C2_omode"]
+    sph, ns, _ = _scene(apt, case, torch)
+    for b, c in case["ranges"]:
+        fb, u8 = apt.render.render_frame(_params(apt, case, ns), sph, b, c)
+        torch.cuda.synchronize()
+        _check_ranges(case, fb, u8, b, "C2 O-mode")
+
+
+@pytest.mark.gpu
+def test_c5_as_named_32_bounces_with_russian_roulette(apt):
+    """BASELINE configs[4] as named: 1080p, 256 spp, depth 32, APT_FLAG_RR (rr_start 3) -- with the wave-queue
+    compaction (the timed C5 configuration) and without it."""
+    _whole_frame(apt, "C5_rr", [apt.APT_FLAG_RR | apt.APT_FLAG_RETIRE, apt.APT_FLAG_RR])
+
+
+@pytest.mark.gpu
+def test_c5_32_bounces_full_trace(apt):
+    _whole_frame(apt, "C5_full", [0, apt.APT_FLAG_RETIRE])
+
+
+@pytest.mark.gpu
+def test_c3_band_edges_of_all_eight_ranks(apt):
+    """BASELINE configs[2] (4096x4096, 1024 spp): each of the 8 ranks' bands rendered as that rank would render it
+    (one launch per band, 17.2 G segments each), first and last image column compared."""
+    import torch
+    from ascendpathtracing_amd import dist as apt_dist
+    case = HASHES["C3_bands"]
+    sph, ns, _ = _scene(apt, case, torch)
+    npix = case["w"] * case["h"]
+    for r in range(8):
+        b, c = apt_dist.split_range(npix, r, 8)
+        fb, u8 = apt.render.render_frame(_params(apt, case, ns), sph, b, c)
+        torch.cuda.synchronize()
+        _check_ranges(case, fb, u8, b, f"C3 band {r}")
+    assert len(case["ranges"]) == 16
+
+
+@pytest.mark.gpu
+def test_c4_ten_thousand_spheres(apt):
+    """BASELINE configs[3]: a whole 480x270 frame by brute force (LDS tiles) and through the grid, then the real
+    1080p / 256 spp frame through the grid (ranges hashed) and by brute force on those ranges only."""
+    import torch
+    case = HASHES["C4_crop"]
+    sph, ns, grid = _scene(apt, case, torch)
+    for accel, flags in ((0, 0), (grid.data_ptr(), 0), (grid.data_ptr(), apt.APT_FLAG_RETIRE)):
+        fb, u8 = apt.render.render_frame(_params(apt, case, ns, flags=flags, accel=accel), sph)
+        torch.cuda.synchronize()
+        _check_ranges(case, fb, u8, 0, f"C4 crop accel={bool(accel)} flags={flags}")
+    case = HASHES["C4_1080p"]
+    fb, u8 = apt.render.render_frame(_params(apt, case, ns, accel=grid.data_ptr()), sph)
+    torch.cuda.synchronize()
+    _check_ranges(case, fb, u8, 0, "C4 1080p grid")
+    for b, c in case["ranges"]:
+        fb, u8 = apt.render.render_frame(_params(apt, case, ns), sph, b, c)
+        torch.cuda.synchronize()
+        _check_ranges(case, fb, u8, b, "C4 1080p brute force")
+
+
+def test_committed_hashes_are_the_oracles(oracle):
+    """CPU: the committed file has every BASELINE configuration and still equals what the oracle computes
+    (re-run on the cheapest ranges: two C3 band edges, one C2 O-mode range, one C2 chunk prefix is too large)."""
+    assert set(HASHES) >= {"C2", "C2_omode", "C5_rr", "C5_full", "C3_bands", "C4_crop", "C4_1080p"}
+    for name, case in HASHES.items():
+        assert len(case["ranges"]) == len(case["fb_sha256"]) == len(case["u8_sha256"]), name
+    for name, picks in (("C3_bands", [0, 15]), ("C2_omode", [3])):
+        case = HASHES[name]
+        p = oracle.make_params(case["w"], case["h"], case["s"], depth=case["depth"],
+                               mode=oracle.MODE_O if case["mode"] == "O" else oracle.MODE_K,
+                               flags=case["flags"] | oracle.FLAG_RETIRE, seed=case["seed"])
+        for k in picks:
+            b, c = case["ranges"][k]
+            fb, u8, _, _ = oracle.render_frame(p, oracle.gen_spheres(), pixel_begin=b, pixel_count=c,
+                                               threads=min(8, oracle.max_threads()))
+            assert sha(fb) == case["fb_sha256"][k] and sha(u8) == case["u8_sha256"][k], (name, k)

@@ -1,0 +1,155 @@
+"""GPU tests of the drop-in boundary itself (run with -m gpu): the reference's C++-linkage declaration called
+through unmodified, the per-call error record, contexts used from several host threads, the host-pointer
+(CPU-simulator shaped) entry and the one-process multi-GPU object.  All results bit-exact."""
+import ctypes
+import threading
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+def bits(a):
+    if isinstance(a, torch.Tensor):
+        a = a.detach().cpu().numpy()
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+@pytest.fixture(scope="module")
+def apt():
+    import __graft_entry__ as g
+    g.build()
+    import ascendpathtracing_amd as pkg
+    from ascendpathtracing_amd import _lib, gen_data, render
+    _lib.require_gpu()
+    pkg.render, pkg.gen_data = render, gen_data
+    return pkg
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32).ravel()).cuda()
+
+
+def test_reference_cxx_declaration_calls_through(apt, golden, oracle, tmp_path):
+    """A TU with src/main.cpp:9-10's declaration verbatim (C++ linkage), compiled by g++ and linked against the
+    library unchanged, drives the GPU: same colours as the CPU restatement."""
+    from test_host_abi import build_reference_decl_shim
+    data, _ = golden
+    shim = ctypes.CDLL(build_reference_decl_shim(apt, str(tmp_path)))
+    shim.call_through_reference_declaration.restype = None
+    rays, sph = dev(data["16x16_s1_rays"]), dev(data["spheres"])
+    colors = torch.full((3 * 1024,), float("nan"), device="cuda")
+    apt.render.set_default_params(apt.default_params())
+    shim.call_through_reference_declaration(ctypes.c_uint32(8), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream),
+                                            ctypes.c_void_p(rays.data_ptr()), ctypes.c_void_p(sph.data_ptr()),
+                                            ctypes.c_void_p(colors.data_ptr()))
+    torch.cuda.synchronize()
+    assert apt._lib.lib().apt_last_status() == 0
+    want, _ = oracle.render_paths(oracle.make_params(16, 16, 1, depth=5, mode=oracle.MODE_K), data["16x16_s1_rays"],
+                                  data["spheres"])
+    assert np.array_equal(bits(colors), bits(want).ravel())
+
+
+def test_failed_call_does_not_poison_the_next_render_do(apt, golden, oracle):
+    """the error record was only ever set.  A rejected call followed by a good render_do on the same
+    thread must succeed (the Python wrapper raises on a non-zero status)."""
+    data, _ = golden
+    rays, sph = dev(data["16x16_s1_rays"]), dev(data["spheres"])
+    colors = torch.zeros(3 * 1024, device="cuda")
+    with pytest.raises(apt.AptError):
+        apt.render.render_do_ex(apt.make_params(16, 16, 1, path_begin=10 ** 9), None, rays, sph, colors)
+    with pytest.raises(apt.AptError):
+        apt.render.set_refill_lanes(0)
+    apt.render.set_default_params(apt.default_params())
+    apt.render.render_do(8, None, None, rays, sph, colors)         # must not raise
+    torch.cuda.synchronize()
+    want, _ = oracle.render_paths(oracle.make_params(16, 16, 1, depth=5), data["16x16_s1_rays"], data["spheres"])
+    assert np.array_equal(bits(colors), bits(want).ravel())
+    assert apt._lib.lib().apt_last_error() == b""
+
+
+def test_contexts_render_different_sizes_from_two_threads(apt, golden, oracle):
+    """Two host threads, two contexts with different parameters, each on its own stream, interleaved calls:
+    every result equals the oracle's for ITS parameters (the process-wide defaults would race)."""
+    data, _ = golden
+    sph = dev(data["spheres"])
+    jobs = {"a": ("16x16_s1", 16, 16, 1, 5), "b": ("32x32_s1", 32, 32, 1, 8)}
+    out, errs = {}, []
+
+    def work(tag):
+        try:
+            key, w, h, s, d = jobs[tag]
+            rays = dev(data[f"{key}_rays"])
+            ctx = apt.render.Context(apt.make_params(w, h, s, depth=d))
+            stream = torch.cuda.Stream()
+            res = []
+            for _ in range(20):
+                colors = torch.zeros(3 * w * h * 4 * s, device="cuda")
+                ctx.render_do(8, None, stream, rays, sph, colors)
+                res.append(colors)
+            stream.synchronize()
+            out[tag] = res
+            ctx.close()
+        except Exception as e:   # noqa: BLE001
+            errs.append((tag, repr(e)))
+
+    ts = [threading.Thread(target=work, args=(t,)) for t in jobs]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errs, errs
+    for tag, (key, w, h, s, d) in jobs.items():
+        want, _ = oracle.render_paths(oracle.make_params(w, h, s, depth=d), data[f"{key}_rays"], data["spheres"])
+        for colors in out[tag]:
+            assert np.array_equal(bits(colors), bits(want).ravel()), tag
+
+
+def test_context_refill_knob_and_counter_are_private(apt, oracle):
+    sph = dev(oracle.gen_spheres())
+    p = apt.make_params(24, 10, 16, depth=8, flags=apt.APT_FLAG_RETIRE, seed=3)
+    ref, ref8 = apt.render.render_frame(p, sph)
+    ctx = apt.render.Context()
+    ctx.set_refill_lanes(5)
+    counter = torch.zeros(4, dtype=torch.int64, device="cuda")
+    ctx.set_trace_counter(counter)
+    fb, u8 = ctx.render_frame(p, sph)
+    torch.cuda.synchronize()
+    assert torch.equal(fb.view(torch.int32), ref.view(torch.int32)) and torch.equal(u8, ref8)
+    _, _, _, traced = oracle.render_frame(oracle.make_params(24, 10, 16, depth=8, flags=oracle.FLAG_RETIRE, seed=3),
+                                          oracle.gen_spheres())
+    assert int(counter[0]) == traced
+    with apt.render.TraceCounter() as tc:        # the default context's counter saw nothing of ctx's launch
+        pass
+    assert tc.value == 0
+    ctx.close()
+
+
+def test_host_pointer_entry_cpu_simulator_shape(apt, golden, oracle):
+    """apt_render_host: HOST buffers in and out, synchronous (the ICPU_RUN_KF(render, ...) shape, src/main.cpp:37)."""
+    data, _ = golden
+    rays = np.ascontiguousarray(data["16x16_s2_rays"], dtype=np.float32).ravel()
+    sph = np.ascontiguousarray(data["spheres"], dtype=np.float32)
+    colors = np.zeros(3 * 16 * 16 * 4 * 2, dtype=np.float32)
+    apt.render.set_default_params(apt.make_params(16, 16, 2, depth=5, mode=apt.APT_MODE_ORACLE))
+    apt.render.render_host(8, rays, sph, colors)
+    apt.render.set_default_params(apt.default_params())
+    assert np.array_equal(bits(colors), bits(data["16x16_s2_d5_soa"]).ravel())      # == the reference's test_soa.bin
+
+
+@pytest.mark.parametrize("bands,stripes", [(1, 1), (2, 1), (3, 1), (2, 5), (4, 3)])
+def test_one_process_multi_gpu_object(apt, oracle, bands, stripes):
+    """apt_multi on ONE physical GPU (every band on device 0: separate streams, peer-copy path device 0 -> 0):
+    contiguous bands and interleaved stripes give the single-launch frame bit for bit, uneven splits included."""
+    sph_host = oracle.gen_spheres()
+    p = apt.make_params(37, 23, 16, depth=6, seed=11)                  # 851 pixels: not divisible by 2, 3, 10 or 12
+    ref, ref8 = apt.render.render_frame(p, dev(sph_host))
+    mg = apt.render.MultiGpu(p, sph_host, [0] * bands, stripes=stripes)
+    for _ in range(2):
+        fb, u8 = mg.render()
+        assert torch.equal(fb.view(torch.int32), ref.view(torch.int32)) and torch.equal(u8, ref8)
+    assert len(mg.band_kernel_ms) == bands and all(ms >= 0 for ms in mg.band_kernel_ms)
+    mg.close()
+    with pytest.raises(apt.AptError):
+        apt.render.MultiGpu(p, sph_host, [0, 99])

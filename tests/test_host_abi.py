@@ -32,7 +32,7 @@ def test_every_declared_symbol_is_exported(apt):
     for name in sorted(declared):
         assert hasattr(h, name), f"{name} declared in include/render_mi355x.h but not exported"
     assert set(apt._lib.ABI_SYMBOLS) == declared
-    assert h.apt_abi_version() == 1
+    assert h.apt_abi_version() == 2
 
 
 def test_params_struct_layout_matches_header(apt):
@@ -205,4 +205,92 @@ def test_header_is_plain_c_and_links_from_c(apt, tmp_path):
     subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"), str(src),
                     "-o", str(exe), "-L", libdir, "-lrender_mi355x", "-Wl,-rpath," + libdir], check=True)
     out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()
-    assert out == ["16", "16", "1", "5", "1", "272.25"]
+    assert out == ["16", "16", "1", "5", "2", "272.25"]
+
+
+# The reference's own declaration of the boundary, verbatim from src/main.cpp:9-10 (an interface, not code):
+# C++ linkage, no extern "C".  A translation unit holding it must link against the library unchanged.
+REF_DECL_TU = r"""
+#include <stdint.h>
+extern void render_do(uint32_t coreDim, void *l2ctrl, void *stream,
+                      uint8_t *rays, uint8_t *spheres,uint8_t *colors);
+extern "C" void call_through_reference_declaration(uint32_t coreDim, void *stream, uint8_t *rays, uint8_t *spheres,
+                                                   uint8_t *colors) {
+    render_do(coreDim, nullptr, stream, rays, spheres, colors);   // src/main.cpp:74
+}
+"""
+
+
+def build_reference_decl_shim(apt, out_dir):
+    """g++-compiles REF_DECL_TU into a shared object linked against librender_mi355x.so -> its path."""
+    import subprocess
+    src = os.path.join(out_dir, "ref_decl_tu.cpp")
+    so = os.path.join(out_dir, "libref_decl_tu.so")
+    with open(src, "w") as f:
+        f.write(REF_DECL_TU)
+    libdir = os.path.dirname(apt._lib.LIB_PATH)
+    subprocess.run(["g++", "-O1", "-std=c++17", "-shared", "-fPIC", "-Wl,--no-undefined", src, "-o", so, f"-L{libdir}",
+                    "-lrender_mi355x", f"-Wl,-rpath,{libdir}"], check=True)
+    return so
+
+
+def test_reference_cxx_declaration_links_unmodified(apt, tmp_path):
+    """src/main.cpp:9-10 declares render_do with C++ linkage: the library exports the mangled symbol, so a TU with
+    that declaration links (--no-undefined) without touching the declaration."""
+    import subprocess
+    so = build_reference_decl_shim(apt, str(tmp_path))
+    undefined = subprocess.run(["nm", "-D", "--undefined-only", so], capture_output=True, text=True, check=True).stdout
+    assert "_Z9render_dojPvS_PhS0_S0_" in undefined            # the TU really binds the C++-mangled name
+    exported = subprocess.run(["nm", "-D", "--defined-only", apt._lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    assert " T _Z9render_dojPvS_PhS0_S0_" in exported and " T render_do\n" in exported and " T apt_render_do" in exported
+
+
+def test_error_record_is_per_call(apt):
+    """apt_last_error()/apt_last_status() describe the LAST call on this thread: a failure must not stick."""
+    h = apt._lib.lib()
+    bad = apt.default_params()
+    bad.num_spheres = 0
+    assert h.apt_set_default_params(ctypes.byref(bad)) != 0
+    assert h.apt_last_status() != 0 and b"num_spheres" in h.apt_last_error()
+    assert h.apt_gen_spheres_host(None) == 1 and b"apt_gen_spheres_host" in h.apt_last_error()   # host helpers set it too
+    buf = np.zeros(128, dtype=np.float32)
+    assert h.apt_gen_spheres_host(buf.ctypes.data_as(ctypes.c_void_p)) == 0
+    assert h.apt_last_status() == 0 and h.apt_last_error() == b""
+    assert h.apt_write_ppm(b"/nonexistent_dir/x.ppm", 1, 1, buf.ctypes.data_as(ctypes.c_void_p)) == 5
+    assert b"/nonexistent_dir/x.ppm" in h.apt_last_error()
+    assert h.apt_set_default_params(ctypes.byref(apt.default_params())) == 0 and h.apt_last_error() == b""
+
+
+def test_contexts_are_independent_and_thread_safe(apt):
+    """Setters of one context do not leak into another or into the default one; concurrent setters on one
+    context do not corrupt it (no GPU needed: only the host-side state is exercised)."""
+    import threading
+    h = apt._lib.lib()
+    h.apt_context_create.restype = ctypes.c_void_p
+    a, b = ctypes.c_void_p(h.apt_context_create()), ctypes.c_void_p(h.apt_context_create())
+    assert a and b
+    pa = apt.make_params(64, 32, 2, depth=7)
+    assert h.apt_context_set_params(a, ctypes.byref(pa)) == 0
+    bad = apt.default_params()
+    bad.struct_size = 4
+    assert h.apt_context_set_params(b, ctypes.byref(bad)) == 2          # APT_ERR_STRUCT, b unchanged
+    assert h.apt_context_set_refill_lanes(a, 0) == 1 and h.apt_context_set_refill_lanes(a, 64) == 0
+    assert h.apt_context_set_params(None, ctypes.byref(pa)) == 1
+    errs = []
+
+    def hammer(ctx, k):
+        for i in range(2000):
+            p = apt.make_params(16 + k, 16 + k, 1 + (i & 3), depth=k + 1)
+            if h.apt_context_set_params(ctx, ctypes.byref(p)) != 0 or h.apt_last_status() != 0:
+                errs.append((k, i))
+            q = apt.default_params()
+            q.num_spheres = 0
+            if h.apt_context_set_params(ctx, ctypes.byref(q)) != 3 or b"num_spheres" not in h.apt_last_error():
+                errs.append(("err", k, i))
+
+    ts = [threading.Thread(target=hammer, args=(a, k)) for k in range(4)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errs
+    h.apt_context_destroy(a)
+    h.apt_context_destroy(b)
