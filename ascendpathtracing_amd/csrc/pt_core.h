@@ -249,22 +249,27 @@ APT_HD void rootkey_update(RootKey &k, float t0, float t1, int sphere) {
 APT_HD float rootkey_tmin(const RootKey &k) { return bits_f32(k.best + k.bias); }
 APT_HD bool eps_allows_rootkey(float eps) { return eps > 0.0f && eps < kMissT; }
 
-// State of one path between bounces.
+#if defined(__clang__) // everything from here to the matching #endif is used by the kernels only (hipcc = clang)
+// State of one path between bounces.  The x and y components of the three 3-vectors are kept as register PAIRS
+// (ext_vector float2): the bounce block runs them through packed v_pk_*_f32 instructions, and a pair built on
+// the fly from two scalars would cost a register copy per bounce.
+typedef float f2 __attribute__((ext_vector_type(2)));
 struct PathState {
-    float ox, oy, oz, dx, dy, dz; // ray (updated in place, rt_helper.h:699-708)
-    float rx, ry, rz;             // throughput `ret` (render.cpp:116-121)
+    f2 oxy, dxy;                  // ray (updated in place, rt_helper.h:699-708)
+    f2 rxy;                       // throughput `ret` (render.cpp:116-121)
+    float oz, dz, rz;
     uint32_t alive;               // retMask bit (render.cpp:123-124); a dword so the struct has no padding
 };
 
 APT_HD void path_init(PathState &s, float ox, float oy, float oz, float dx, float dy, float dz) {
-    s.ox = ox; s.oy = oy; s.oz = oz; s.dx = dx; s.dy = dy; s.dz = dz;
-    s.rx = 1.0f; s.ry = 1.0f; s.rz = 1.0f;
+    s.oxy = f2{ox, oy}; s.oz = oz; s.dxy = f2{dx, dy}; s.dz = dz;
+    s.rxy = f2{1.0f, 1.0f}; s.rz = 1.0f;
     s.alive = 1u;
 }
 
 // A finished path: nothing a further bounce does can change its colour (Appendix A notes).
 APT_HD bool path_finished(const PathState &s) {
-    return !s.alive || (s.rx == 0.0f && s.ry == 0.0f && s.rz == 0.0f);
+    return !s.alive || (s.rxy.x == 0.0f && s.rxy.y == 0.0f && s.rz == 0.0f);
 }
 
 // GenerateNewRays + AccumulateIntervalColor for the hit (tmin, sphere centre c, albedo col).
@@ -272,8 +277,8 @@ APT_HD bool path_finished(const PathState &s) {
 template <int MODE, bool FAST = false>
 APT_HD void shade_and_reflect(PathState &s, float tmin, float cx, float cy, float cz, float colx, float coly,
                               float colz, bool is_light, float *amin = nullptr) {
-    float hx = s.dx * tmin, hy = s.dy * tmin, hz = s.dz * tmin; // rt_helper.h:513-518
-    hx = s.ox + hx; hy = s.oy + hy; hz = s.oz + hz;
+    float hx = s.dxy.x * tmin, hy = s.dxy.y * tmin, hz = s.dz * tmin; // rt_helper.h:513-518
+    hx = s.oxy.x + hx; hy = s.oxy.y + hy; hz = s.oz + hz;
     float nx = hx - cx, ny = hy - cy, nz = hz - cz;             // :635-637
     float L;
     if (MODE == kModeOracle) {                                  // np.linalg.norm, gen_data.py:347
@@ -307,25 +312,27 @@ APT_HD void shade_and_reflect(PathState &s, float tmin, float cx, float cy, floa
     }
     float dot;
     if (MODE == kModeOracle) {                                  // np.dot, gen_data.py:349
-        float p0 = s.dx * ux, p1 = s.dy * uy, p2 = s.dz * uz;
+        float p0 = s.dxy.x * ux, p1 = s.dxy.y * uy, p2 = s.dz * uz;
         double acc = 0.0 + (double)p0;
         acc = acc + (double)p1;
         acc = acc + (double)p2;
         dot = (float)acc;
     } else {
-        dot = 0.0f + s.dx * ux;                                 // :690 Duplicate(0), :694-696
-        dot = dot + s.dy * uy;
+        dot = 0.0f + s.dxy.x * ux;                                 // :690 Duplicate(0), :694-696
+        dot = dot + s.dxy.y * uy;
         dot = dot + s.dz * uz;
     }
     float k2 = dot * 2.0f;                                      // :697
     float mx = ux * k2, my = uy * k2, mz = uz * k2;             // :699-701
-    s.dx = s.dx - mx; s.dy = s.dy - my; s.dz = s.dz - mz;       // :702-704
-    s.ox = hx; s.oy = hy; s.oz = hz;                            // :706-708
+    s.dxy.x = s.dxy.x - mx; s.dxy.y = s.dxy.y - my; s.dz = s.dz - mz;       // :702-704
+    s.oxy.x = hx; s.oxy.y = hy; s.oz = hz;                            // :706-708
     s.alive = (s.alive && !is_light) ? 1u : 0u;                 // :773-787
     if (s.alive) {                                              // :799-810 (x1 is exact otherwise)
-        s.rx = colx * s.rx; s.ry = coly * s.ry; s.rz = colz * s.rz;
+        s.rxy.x = colx * s.rxy.x; s.rxy.y = coly * s.rxy.y; s.rz = colz * s.rz;
     }
 }
+
+#endif // __clang__
 
 // ---- first-hit debug mode: scripts/gen_data.py:134-188 test_scene --------------------------
 // One ray against sphere k with test_scene's arithmetic: np.dot on float32 3-vectors (float64
@@ -552,19 +559,22 @@ constexpr uint32_t kGridMagic = 0x47524944u; // "GRID"
 
 // ---- Russian roulette (extension, APT_FLAG_RR; specified in include/render_mi355x.h) ------------
 APT_HD uint64_t rr_path_key(uint64_t seed, uint64_t path) { return splitmix64(seed ^ splitmix64(path)); }
+#if defined(__clang__)
 APT_HD void russian_roulette(PathState &s, uint64_t key, uint32_t bounce) { // bounce: 0-based index just shaded
     if (!s.alive) return;                       // frozen after the light: throughput no longer changes
-    float q = s.rx;
-    if (s.ry > q) q = s.ry;
+    float q = s.rxy.x;
+    if (s.rxy.y > q) q = s.rxy.y;
     if (s.rz > q) q = s.rz;
     if (!(q > 0.0f)) return;                    // already (0,0,0), negative or NaN: leave it
     float p = q < 0.05f ? 0.05f : q;
     p = p > 0.95f ? 0.95f : p;
     const uint64_t h = splitmix64(key + 0x9E3779B97F4A7C15ull * (uint64_t)(bounce + 1u));
     const float u = (float)(uint32_t)(h >> 40) * 0x1p-24f;
-    if (u >= p) { s.rx = 0.0f; s.ry = 0.0f; s.rz = 0.0f; }
-    else { const float inv = 1.0f / p; s.rx = s.rx * inv; s.ry = s.ry * inv; s.rz = s.rz * inv; }
+    if (u >= p) { s.rxy.x = 0.0f; s.rxy.y = 0.0f; s.rz = 0.0f; }
+    else { const float inv = 1.0f / p; s.rxy.x = s.rxy.x * inv; s.rxy.y = s.rxy.y * inv; s.rz = s.rz * inv; }
 }
+
+#endif // __clang__
 
 // path index -> (i, j, sy, sx, k):  p = (((i*H + j)*2 + sy)*2 + sx)*S + k   gen_data.py:32-36
 APT_HD void path_coords(uint64_t p, uint32_t H, uint32_t S, uint32_t &i, uint32_t &j, uint32_t &sy, uint32_t &sx) {

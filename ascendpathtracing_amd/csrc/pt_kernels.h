@@ -30,8 +30,8 @@ __global__ __launch_bounds__(kBlock, SC == kSceneGrid ? APT_GRID_WAVES : 1) void
     else traced = trace_dyn<MODE, RETIRE>(sph, tile, s, valid, ta, p);
     if (valid) {                                          // render.cpp:194-196, CopyOut :210-223
         const Gain3 gain = load_gain(sph, ta);
-        colors[p] = s.rx * gain.r;
-        colors[n_total + p] = s.ry * gain.g;
+        colors[p] = s.rxy.x * gain.r;
+        colors[n_total + p] = s.rxy.y * gain.g;
         colors[2 * n_total + p] = s.rz * gain.b;
     }
     count_traced(ta, valid ? traced : 0);
@@ -91,8 +91,8 @@ __global__ __launch_bounds__(kBlock) void render_paths_queue_kernel(const float 
         depth_left -= active ? 1u : 0u;
         if (active && (depth_left == 0 || path_finished(s))) {
             depth_left = 0;
-            colors[cur] = s.rx * gain.r;
-            colors[n_total + cur] = s.ry * gain.g;
+            colors[cur] = s.rxy.x * gain.r;
+            colors[n_total + cur] = s.rxy.y * gain.g;
             colors[2 * n_total + cur] = s.rz * gain.b;
         }
     }
@@ -158,7 +158,7 @@ __global__ __launch_bounds__(kBlock, (RETIRE && SC == kScene8 && GROUP == 8) ? 5
         if (SC == kScene8) traced += trace_ns8<MODE, RETIRE>(sc, tab8, s, valid, ta, pbase + k);
         else if (SC == kSceneGrid) traced += trace_grid<MODE, RETIRE>(sph, ta.grid, s, valid, ta, pbase + k);
         else traced += trace_dyn<MODE, RETIRE>(sph, tile, s, valid, ta, pbase + k);
-        return Col{s.rx * gain.r, s.ry * gain.g, s.rz * gain.b};
+        return Col{s.rxy.x * gain.r, s.rxy.y * gain.g, s.rz * gain.b};
     };
     auto add = [](const Col &a, const Col &b) { return Col{a.r + b.r, a.g + b.g, a.b + b.b}; };
 
@@ -258,8 +258,8 @@ __global__ __launch_bounds__(kBlock, (RETIRE && SC == kScene8 && GROUP == 8) ? 5
                     depth_left -= active ? 1u : 0u;
                     if (active && (depth_left == 0 || path_finished(s))) {
                         depth_left = 0;
-                        colq[cur_item] = s.rx * gain.r;
-                        colq[qstride + cur_item] = s.ry * gain.g;
+                        colq[cur_item] = s.rxy.x * gain.r;
+                        colq[qstride + cur_item] = s.rxy.y * gain.g;
                         colq[2 * qstride + cur_item] = s.rz * gain.b;
                     }
                 }

@@ -66,7 +66,7 @@ struct LeafProg { // numpy pairwise_sum recursion flattened (see build_leaves)
 // so every operation of intersect_pre becomes one v_pk_{add,mul}_f32 over a register pair, the
 // ray component being broadcast to both halves by op_sel (no register shuffles).  Packed fp32
 // ops round exactly like the scalar ones, element by element; contraction is off.
-typedef float f2 __attribute__((ext_vector_type(2)));
+
 struct HitPre2 { f2 b, disc; };
 __device__ __forceinline__ HitPre2 intersect_pre2(const f2 cx, const f2 cy, const f2 cz, const f2 r2, float ox,
                                                   float oy, float oz, float dx, float dy, float dz) {
@@ -105,7 +105,7 @@ __device__ __forceinline__ bool bounce_ns8(const Scene8 &sc, const Tab8 tab, con
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             float t0, t1;
-            intersect_roots<true>(sc.cx[k], sc.cy[k], sc.cz[k], sc.r2[k], s.ox, s.oy, s.oz, s.dx, s.dy, s.dz, t0, t1,
+            intersect_roots<true>(sc.cx[k], sc.cy[k], sc.cz[k], sc.r2[k], s.oxy.x, s.oxy.y, s.oz, s.dxy.x, s.dxy.y, s.dz, t0, t1,
                                   amin);
             rootkey_update(key, t0, t1, k);
         }
@@ -113,8 +113,8 @@ __device__ __forceinline__ bool bounce_ns8(const Scene8 &sc, const Tab8 tab, con
 #pragma unroll
         for (int k = 0; k < 8; k += 2) { // rt_helper.h:457-467, two spheres per packed instruction
             const HitPre2 h = intersect_pre2(f2{sc.cx[k], sc.cx[k + 1]}, f2{sc.cy[k], sc.cy[k + 1]},
-                                             f2{sc.cz[k], sc.cz[k + 1]}, f2{sc.r2[k], sc.r2[k + 1]}, s.ox, s.oy, s.oz,
-                                             s.dx, s.dy, s.dz);
+                                             f2{sc.cz[k], sc.cz[k + 1]}, f2{sc.r2[k], sc.r2[k + 1]}, s.oxy.x, s.oxy.y, s.oz,
+                                             s.dxy.x, s.dxy.y, s.dz);
             // sqrt_rn_rsq1 on both lanes of the pair (pt_core.h): y = x*r, hh = r/2, q = fma(fma(-y,y,x), hh, y)
             amin = fminf(amin, fminf(fabsf(h.disc.x), fabsf(h.disc.y)));
             const f2 r0 = {__builtin_amdgcn_rsqf(h.disc.x), __builtin_amdgcn_rsqf(h.disc.y)};
@@ -134,7 +134,7 @@ __device__ __forceinline__ bool bounce_ns8(const Scene8 &sc, const Tab8 tab, con
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             float t0, t1;
-            intersect_roots<false>(sc.cx[k], sc.cy[k], sc.cz[k], sc.r2[k], s.ox, s.oy, s.oz, s.dx, s.dy, s.dz, t0, t1,
+            intersect_roots<false>(sc.cx[k], sc.cy[k], sc.cz[k], sc.r2[k], s.oxy.x, s.oxy.y, s.oz, s.dxy.x, s.dxy.y, s.dz, t0, t1,
                                    amin);
             const float t = select_root(t0, t1, ta.eps);
             if (t < tmin) { tmin = t; idx = k; } // strict '<', ascending k: lowest index wins ties
@@ -190,12 +190,42 @@ __device__ __forceinline__ uint32_t select_const(uint64_t mask, uint32_t value_i
 // -> wave mask of the lanes that left the validity range of the fast sequences (exact re-run wanted)
 // `alive`: wave mask of the lanes whose path has not reached the light (in: before, out: after this bounce);
 // s.alive / n.alive are not read or written here (callers that need the per-lane form make it from the mask).
+struct Albedo { f2 xy; float z; };
+// ret *= albedo for the lanes of `alive`, in place: the three products run under exec = alive (an s_and_saveexec /
+// restore pair on the scalar unit) instead of through three selects; other lanes keep their value (x1 is exact).
+__device__ __forceinline__ void apply_albedo(f2 &rxy, float &rz, const Albedo &a, uint64_t alive) {
+    uint64_t saved;
+    asm volatile("s_and_saveexec_b64 %[sv], %[m]\n\t"
+                 "v_pk_mul_f32 %[rxy], %[cxy], %[rxy]\n\t"
+                 "v_mul_f32 %[rz], %[cz], %[rz]\n\t"
+                 "s_mov_b64 exec, %[sv]"
+                 : [sv] "=&s"(saved), [rxy] "+v"(rxy), [rz] "+v"(rz)
+                 : [m] "s"(alive), [cxy] "v"(a.xy), [cz] "v"(a.z));
+}
+
 template <int MODE>
 __device__ __forceinline__ uint64_t bounce_ns8_v2(const Scene8 &sc, const Tab8 tab, const PathState &s, PathState &n,
-                                                  const TraceArgs &ta, const KeyConsts &kc, uint64_t &alive) {
+                                                  const TraceArgs &ta, const KeyConsts &kc, uint64_t &alive, Albedo &albedo) {
     float amin = 1.0f;
     uint32_t best = kc.init;
     uint64_t b0 = 0, b1 = 0, b2 = 0, any = 0;
+#ifdef APT_T_EXTRA // measurement only (profiles/microbench/insitu_costs.sh): N extra independent instructions of one class per bounce
+    {
+        float x0 = s.oxy.x, x1 = s.oxy.y, x2 = s.oz, x3 = s.dxy.x;
+        f2 y0 = {s.oxy.x, s.oxy.y}, y1 = {s.oz, s.dxy.x};
+#define APT_R4(a) a a a a
+#if APT_T_EXTRA == 1   // 16 plain
+#define APT_T_OPS "v_add_f32 %0, %0, %6\n v_add_f32 %1, %1, %6\n v_add_f32 %2, %2, %7\n v_add_f32 %3, %3, %7\n"
+#elif APT_T_EXTRA == 2 // 16 min (half-rate class)
+#define APT_T_OPS "v_min_f32 %0, %0, %6\n v_min_f32 %1, %1, %6\n v_min_f32 %2, %2, %7\n v_min_f32 %3, %3, %7\n"
+#elif APT_T_EXTRA == 3 // 8 packed
+#define APT_T_OPS "v_pk_add_f32 %4, %4, %5\n v_pk_mul_f32 %5, %5, %4\n"
+#else                  // 4 transcendental
+#define APT_T_OPS "v_rsq_f32 %0, %0\n"
+#endif
+        asm volatile(APT_R4(APT_T_OPS) : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(y0), "+v"(y1) : "v"(s.dxy.y), "v"(s.dz));
+    }
+#endif
     auto update = [&](float t0, float t1, int k) {
         const uint32_t m0 = f32_bits(t0) - kc.bias, m1 = f32_bits(t1) - kc.bias;
         const uint32_t nb = min3_u32(best, m0, m1);
@@ -209,7 +239,7 @@ __device__ __forceinline__ uint64_t bounce_ns8_v2(const Scene8 &sc, const Tab8 t
 #pragma unroll
     for (int k = 0; k < 8; k += 2) { // rt_helper.h:457-467, two spheres per packed instruction
         const HitPre2 h = intersect_pre2(f2{sc.cx[k], sc.cx[k + 1]}, f2{sc.cy[k], sc.cy[k + 1]}, f2{sc.cz[k], sc.cz[k + 1]},
-                                         f2{sc.r2[k], sc.r2[k + 1]}, s.ox, s.oy, s.oz, s.dx, s.dy, s.dz);
+                                         f2{sc.r2[k], sc.r2[k + 1]}, s.oxy.x, s.oxy.y, s.oz, s.dxy.x, s.dxy.y, s.dz);
         amin = min3_abs(amin, h.disc.x, h.disc.y);
         // sqrt_rn_rsq1 on both lanes of the pair (pt_core.h): y = x*r, hh = r/2, q = fma(fma(-y,y,x), hh, y)
         const f2 r0 = {__builtin_amdgcn_rsqf(h.disc.x), __builtin_amdgcn_rsqf(h.disc.y)};
@@ -234,25 +264,31 @@ __device__ __forceinline__ uint64_t bounce_ns8_v2(const Scene8 &sc, const Tab8 t
     if (MODE == kModeOracle) light_mask &= any;
     const float4 c = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(tab.geo) + addr);
     const float4 col = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(tab.alb) + addr);
-    // GenerateNewRays (rt_helper.h:504-709), as shade_and_reflect<MODE, true>
-    float hx = s.dx * tmin, hy = s.dy * tmin, hz = s.dz * tmin;
-    hx = s.ox + hx; hy = s.oy + hy; hz = s.oz + hz;
-    const float nx = hx - c.x, ny = hy - c.y, nz = hz - c.z;
+    // GenerateNewRays (rt_helper.h:504-709), as shade_and_reflect<MODE, true>, with the x and y components of
+    // every 3-vector operation in ONE packed instruction (v_pk_{mul,add,fma}_f32 round each half exactly like the
+    // scalar instruction; nothing is contracted): in this kernel every VALU instruction costs about one 4-cycle
+    // issue slot whatever its class (measured in place: profiles/r02_insitu_costs.md), so the instruction COUNT
+    // is what the bounce costs and a packed pair is two operations for one slot.
+    const f2 oxy = s.oxy, dxy = s.dxy;
+    const f2 hxy = oxy + dxy * tmin;                           // :513-518  h = o + d*t (mul, then add)
+    const float hz = s.oz + s.dz * tmin;
+    const f2 nxy = hxy - f2{c.x, c.y};                         // :635-637
+    const float nz = hz - c.z;
+    const f2 sq = nxy * nxy;
     float len2;
-    if (MODE == kModeOracle) {
-        const float p0 = nx * nx, p1 = ny * ny, p2 = nz * nz;
-        double acc = 0.0 + (double)p0;
-        acc = acc + (double)p1;
+    if (MODE == kModeOracle) {                                 // np.linalg.norm, gen_data.py:347: float64 accumulation
+        const float p2 = nz * nz;
+        double acc = 0.0 + (double)sq.x;
+        acc = acc + (double)sq.y;
         acc = acc + (double)p2;
         len2 = (float)acc;
     } else {
-        float acc = 0.0f + nx * nx;
-        acc = acc + ny * ny;
+        float acc = sq.x + sq.y;                               // :641-649 (0 + x^2 is x^2: a square is never -0)
         acc = acc + nz * nz;
         len2 = acc;
     }
-    amin = min3_abs(amin, len2, nx);            // sqrt_rn_rsq1's and div3_shared's validity, see pt_core.h
-    amin = min3_abs(amin, ny, nz);
+    amin = min3_abs(amin, len2, nxy.x);            // sqrt_rn_rsq1's and div3_shared's validity, see pt_core.h
+    amin = min3_abs(amin, nxy.y, nz);
     float L;
     {
         const float r0 = __builtin_amdgcn_rsqf(len2);
@@ -260,59 +296,46 @@ __device__ __forceinline__ uint64_t bounce_ns8_v2(const Scene8 &sc, const Tab8 t
         const float r = __builtin_fmaf(-y, y, len2);
         L = __builtin_fmaf(r, h, y);
     }
-    float ux, uy, uz;
-    {   // div3_shared without its own min/flag bookkeeping
+    f2 uxy;
+    float uz;
+    {   // div3_shared (pt_core.h) without its own min/flag bookkeeping, x and y packed
         const float r0 = __builtin_amdgcn_rcpf(L);
         const float e0 = __builtin_fmaf(-L, r0, 1.0f);
         const float r = __builtin_fmaf(e0, r0, r0);
-        float q, e;
-        q = nx * r; e = __builtin_fmaf(-L, q, nx); q = __builtin_fmaf(e, r, q); e = __builtin_fmaf(-L, q, nx);
-        ux = __builtin_fmaf(e, r, q);
-        q = ny * r; e = __builtin_fmaf(-L, q, ny); q = __builtin_fmaf(e, r, q); e = __builtin_fmaf(-L, q, ny);
-        uy = __builtin_fmaf(e, r, q);
-        q = nz * r; e = __builtin_fmaf(-L, q, nz); q = __builtin_fmaf(e, r, q); e = __builtin_fmaf(-L, q, nz);
+        const f2 nL = {-L, -L}, rr = {r, r};
+        f2 q2 = nxy * r;
+        f2 e2 = __builtin_elementwise_fma(nL, q2, nxy);
+        q2 = __builtin_elementwise_fma(e2, rr, q2);
+        e2 = __builtin_elementwise_fma(nL, q2, nxy);
+        uxy = __builtin_elementwise_fma(e2, rr, q2);
+        float q = nz * r, e = __builtin_fmaf(-L, q, nz);
+        q = __builtin_fmaf(e, r, q);
+        e = __builtin_fmaf(-L, q, nz);
         uz = __builtin_fmaf(e, r, q);
     }
+    const f2 pr = dxy * uxy;
+    const float pz = s.dz * uz;
     float dot;
-    if (MODE == kModeOracle) {
-        const float p0 = s.dx * ux, p1 = s.dy * uy, p2 = s.dz * uz;
-        double acc = 0.0 + (double)p0;
-        acc = acc + (double)p1;
-        acc = acc + (double)p2;
+    if (MODE == kModeOracle) {                                 // np.dot, gen_data.py:349
+        double acc = 0.0 + (double)pr.x;
+        acc = acc + (double)pr.y;
+        acc = acc + (double)pz;
         dot = (float)acc;
     } else {
-        dot = 0.0f + s.dx * ux;
-        dot = dot + s.dy * uy;
-        dot = dot + s.dz * uz;
+        dot = 0.0f + pr.x;                                     // :690 Duplicate(0), :694-696
+        dot = dot + pr.y;
+        dot = dot + pz;
     }
-    const float k2 = dot * 2.0f;
-    const float mx = ux * k2, my = uy * k2, mz = uz * k2;
-    n.dx = s.dx - mx; n.dy = s.dy - my; n.dz = s.dz - mz;
-    n.ox = hx; n.oy = hy; n.oz = hz;
-    // AccumulateIntervalColor (rt_helper.h:711-830): alive &= idx != light; ret *= alive ? albedo : 1
+    const float k2 = dot * 2.0f;                               // :697
+    n.dxy = dxy - uxy * k2;                                    // :699-704
+    n.dz = s.dz - uz * k2;
+    n.oxy = hxy; n.oz = hz;                                    // :706-708
+    // AccumulateIntervalColor (rt_helper.h:711-830): alive &= idx != light; ret *= alive ? albedo : 1.  The mask
+    // is updated here; the multiplication itself is apply_albedo(), which the caller runs once it knows that this
+    // bounce stands (no exact re-run): it can then overwrite the throughput registers in place.
     alive &= ~light_mask;
-#ifdef APT_T_NCOPY
-    const float ndx = n.dx, ndy = n.dy, ndz = n.dz, nox = n.ox, noy = n.oy, noz = n.oz;
-    n = s;
-    n.dx = ndx; n.dy = ndy; n.dz = ndz; n.ox = nox; n.oy = noy; n.oz = noz;
-#else
     n.alive = s.alive;
-    n.rx = s.rx; n.ry = s.ry; n.rz = s.rz;
-#endif
-#ifdef APT_T_NOEXEC
-    if (select_const(alive, 1)) { n.rx = col.x * n.rx; n.ry = col.y * n.ry; n.rz = col.z * n.rz; }
-#else
-    {   // the three products under exec = alive (an s_and_saveexec / restore pair instead of three selects)
-        uint64_t saved;
-        asm volatile("s_and_saveexec_b64 %[sv], %[m]\n\t"
-                     "v_mul_f32 %[rx], %[cx], %[rx]\n\t"
-                     "v_mul_f32 %[ry], %[cy], %[ry]\n\t"
-                     "v_mul_f32 %[rz], %[cz], %[rz]\n\t"
-                     "s_mov_b64 exec, %[sv]"
-                     : [sv] "=&s"(saved), [rx] "+v"(n.rx), [ry] "+v"(n.ry), [rz] "+v"(n.rz)
-                     : [m] "s"(alive), [cx] "v"(col.x), [cy] "v"(col.y), [cz] "v"(col.z));
-    }
-#endif
+    albedo = Albedo{f2{col.x, col.y}, col.z};
     const uint64_t tiny = __builtin_amdgcn_ballot_w64(amin < 0x1p-96f);
     const uint64_t huge = __builtin_amdgcn_ballot_w64((int32_t)(0x5d800000u - f32_bits(len2)) < 0); // len2 > 2^60 (or NaN): see div3_shared
     return tiny | huge;
@@ -328,8 +351,9 @@ __device__ __forceinline__ void bounce_ns8_checked(const Scene8 &sc, const Tab8 
                                                    uint64_t &alive, bool want_lane_alive, uint64_t active = ~0ull) {
     const uint64_t alive_in = alive;
     uint64_t redo = ~0ull;
-    if (__builtin_expect(fast_ok, 1)) redo = bounce_ns8_v2<MODE>(sc, tab, s, n, ta, kc, alive);
-#ifndef APT_T_NOCOLD
+    Albedo albedo;
+    bool fast_stands = false;
+    if (__builtin_expect(fast_ok, 1)) { redo = bounce_ns8_v2<MODE>(sc, tab, s, n, ta, kc, alive, albedo); fast_stands = true; }
     if (__builtin_expect((redo & active) != 0, 0)) {
         // A lane left the validity range of the fast sequences (|sqrt argument| < 2^-96, divide operands outside
         // [2^-40, 2^40]).  A lane whose path is already finished (alive bit cleared or throughput zero) cannot
@@ -343,10 +367,14 @@ __device__ __forceinline__ void bounce_ns8_checked(const Scene8 &sc, const Tab8 
             asm volatile("" ::: "memory");
             (void)bounce_ns8<MODE, false>(sc, tab, cold, n, ta);
             alive = __builtin_amdgcn_ballot_w64(n.alive != 0);
+            fast_stands = false;
             if (ta.traced && (threadIdx.x & 63) == 0) atomicAdd(ta.traced + 3, 1ull); // statistics: exact re-runs
         }
     }
-#endif
+    if (__builtin_expect(fast_stands, 1)) {
+        n.rxy = s.rxy; n.rz = s.rz;
+        apply_albedo(n.rxy, n.rz, albedo, alive);
+    }
     if (want_lane_alive) n.alive = select_const(alive, 1);
 }
 
@@ -359,21 +387,76 @@ __device__ __forceinline__ uint32_t trace_ns8(const Scene8 &sc, const Tab8 tab, 
     const bool fast_ok = eps_allows_rootkey(ta.eps);
     const bool lane_alive = RETIRE || ta.rr_start != 0;            // who needs s.alive per lane (wave-uniform)
     uint64_t alive = __builtin_amdgcn_ballot_w64(s.alive != 0);
-    for (uint32_t d = 0; d < ta.depth; ++d) { // render.cpp:140-188
-        const bool fin = RETIRE && (!valid || path_finished(s));
-        if (RETIRE && __all(fin)) break;
-        PathState n;
-        uint64_t alive_n = alive;
-        bounce_ns8_checked<MODE>(sc, tab, s, n, ta, kc, fast_ok, alive_n, lane_alive);
-        if (ta.rr_start && d + 1 >= ta.rr_start) russian_roulette(n, rr_key, d); // wave-uniform branch
-        if (RETIRE) {
+    if (RETIRE) {
+        for (uint32_t d = 0; d < ta.depth; ++d) { // render.cpp:140-188
+            const bool fin = !valid || path_finished(s);
+            if (__all(fin)) break;
+            PathState n;
+            uint64_t alive_n = alive;
+            bounce_ns8_checked<MODE>(sc, tab, s, n, ta, kc, fast_ok, alive_n, true);
+            if (ta.rr_start && d + 1 >= ta.rr_start) russian_roulette(n, rr_key, d); // wave-uniform branch
             if (!fin) { s = n; ++traced; }
             alive = __builtin_amdgcn_ballot_w64(s.alive != 0);
-        } else { // full trace: lanes past the end of the range compute garbage that is never stored
-            s = n;
-            alive = alive_n;
-            ++traced;
         }
+    } else {
+        // Full trace (lanes past the end of the range compute garbage that is never stored).  The hot loop contains
+        // no merge of "fast result" and "exact re-run result" (the register allocator paid for that merge with a
+        // dozen v_mov per bounce on the fast edge): when a bounce must be redone exactly, the wave leaves the loop
+        // and finishes the path's remaining bounces in the exact form (trace_rest_exact) -- about 1e-5 of the
+        // wave-bounces on the demo scene.  Two bounces per loop turn, written out: the second reads the registers
+        // the first wrote and writes the first's inputs, so the new state is not copied back either (the compiler
+        // cannot unroll this loop itself, it contains convergent operations).
+        f2 rxy = s.rxy;   // the throughput lives outside the ping-pong pair and is updated in place
+        float rz = s.rz;
+        auto rest_exact = [&](PathState &from, uint32_t d) { // -> result in s
+            from.alive = select_const(alive, 1);
+            from.rxy = rxy; from.rz = rz;
+            for (; d < ta.depth; ++d) {
+                PathState n;
+                (void)bounce_ns8<MODE, false>(sc, tab, from, n, ta);
+                if (ta.rr_start && d + 1 >= ta.rr_start) russian_roulette(n, rr_key, d);
+                from = n;
+            }
+            if (ta.traced && (threadIdx.x & 63) == 0) atomicAdd(ta.traced + 3, 1ull); // statistics: waves that left the fast loop
+            s = from;
+        };
+        // one fast bounce in -> out (ray only); true when the wave has to go exact from `in` (out is then meaningless)
+        auto step = [&](PathState &in, PathState &out, uint32_t d) -> bool {
+            Albedo albedo;
+            uint64_t alive_out = alive;
+            const uint64_t redo = bounce_ns8_v2<MODE>(sc, tab, in, out, ta, kc, alive_out, albedo);
+            if (__builtin_expect(redo != 0, 0)) {
+                // A lane left the validity range of the fast sequences (|sqrt argument| < 2^-96, divide operands
+                // outside [2^-40, 2^40]).  A lane whose path is already finished (alive bit cleared or throughput
+                // zero) cannot influence any output any more, so its request is ignored: deep all-miss paths
+                // (|n| ~ 1e20) are of that kind.
+                const bool fin = select_const(alive, 1) == 0 || (rxy.x == 0.0f && rxy.y == 0.0f && rz == 0.0f);
+                if (__any(select_const(redo, 1) != 0 && !fin)) return true;
+            }
+            apply_albedo(rxy, rz, albedo, alive_out);   // in place once the bounce stands
+            alive = alive_out;
+            if (ta.rr_start && d + 1 >= ta.rr_start) { // wave-uniform
+                PathState t;
+                t.rxy = rxy; t.rz = rz; t.alive = select_const(alive, 1);
+                russian_roulette(t, rr_key, d);
+                rxy = t.rxy; rz = t.rz;
+            }
+            return false;
+        };
+        traced = ta.depth;
+        PathState n;
+        uint32_t d = 0;
+        if (__builtin_expect(!fast_ok, 0)) { rest_exact(s, 0); return traced; }
+        for (; d + 2 <= ta.depth; d += 2) { // render.cpp:140-188
+            if (__builtin_expect(step(s, n, d), 0)) { rest_exact(s, d); return traced; }
+            if (__builtin_expect(step(n, s, d + 1), 0)) { rest_exact(n, d + 1); return traced; }
+        }
+        if (d < ta.depth) {
+            if (__builtin_expect(step(s, n, d), 0)) { rest_exact(s, d); return traced; }
+            s = n;
+        }
+        s.rxy = rxy; s.rz = rz;
+        if (lane_alive) s.alive = select_const(alive, 1);
     }
     return traced;
 }
@@ -424,8 +507,8 @@ __device__ __forceinline__ uint32_t trace_dyn(const float *__restrict__ sph, flo
             };
             for (uint32_t k = 0; k < n; k += 4) {
                 const float4 a0 = tile[k], c0 = tile[k + 1], a1 = tile[k + 2], c1 = tile[k + 3];
-                const HitPre2 h01 = intersect_pre2(a0, c0, s.ox, s.oy, s.oz, s.dx, s.dy, s.dz);
-                const HitPre2 h23 = intersect_pre2(a1, c1, s.ox, s.oy, s.oz, s.dx, s.dy, s.dz);
+                const HitPre2 h01 = intersect_pre2(a0, c0, s.oxy.x, s.oxy.y, s.oz, s.dxy.x, s.dxy.y, s.dz);
+                const HitPre2 h23 = intersect_pre2(a1, c1, s.oxy.x, s.oxy.y, s.oz, s.dxy.x, s.dxy.y, s.dz);
                 const float m = fmaxf(fmaxf(h01.disc.x, h01.disc.y), fmaxf(h23.disc.x, h23.disc.y)); // NaNs drop out
                 if (__any(m >= 0.0f)) {
                     hit(h01.b.x, h01.disc.x, base + k);
@@ -476,7 +559,7 @@ __device__ __forceinline__ uint32_t trace_grid(const float *__restrict__ sph, co
         float tmin = kMissT;
         int idx = (MODE == kModeOracle) ? -1 : 0;
         auto test_geom = [&](const float4 g, uint32_t k) {
-            const HitPre hp = intersect_pre(g.x, g.y, g.z, g.w, s.ox, s.oy, s.oz, s.dx, s.dy, s.dz);
+            const HitPre hp = intersect_pre(g.x, g.y, g.z, g.w, s.oxy.x, s.oxy.y, s.oz, s.dxy.x, s.dxy.y, s.dz);
             if (hp.disc >= 0.0f) {
                 const float t = intersect_post(hp, ta.eps);
                 if (t < tmin || (t == tmin && (int)k < idx)) { tmin = t; idx = (int)k; }
@@ -488,7 +571,7 @@ __device__ __forceinline__ uint32_t trace_grid(const float *__restrict__ sph, co
         // sphere met again in the next cell -- and once at the end for the winner.
         uint32_t pos = ~0u; // item position of the running minimum, ~0u while `idx` itself is authoritative
         auto test_item = [&](const float4 g, uint32_t i) {
-            const HitPre hp = intersect_pre(g.x, g.y, g.z, g.w, s.ox, s.oy, s.oz, s.dx, s.dy, s.dz);
+            const HitPre hp = intersect_pre(g.x, g.y, g.z, g.w, s.oxy.x, s.oxy.y, s.oz, s.dxy.x, s.dxy.y, s.dz);
             if (hp.disc >= 0.0f) {
                 const float t = intersect_post(hp, ta.eps);
                 if (t < tmin) { tmin = t; pos = i; }
@@ -504,7 +587,7 @@ __device__ __forceinline__ uint32_t trace_grid(const float *__restrict__ sph, co
         // instead of +inf, and neither can beat tmin <= kMissT.
         auto test_large = [&](const float4 g, uint32_t k) {
             ++n_tests;
-            const HitPre hp = intersect_pre(g.x, g.y, g.z, g.w, s.ox, s.oy, s.oz, s.dx, s.dy, s.dz);
+            const HitPre hp = intersect_pre(g.x, g.y, g.z, g.w, s.oxy.x, s.oxy.y, s.oz, s.dxy.x, s.dxy.y, s.dz);
             float q;
 #if defined(__HIP_DEVICE_COMPILE__) // the sqrt variants are device-only builtins
             float am = 1.0f;
@@ -521,7 +604,7 @@ __device__ __forceinline__ uint32_t trace_grid(const float *__restrict__ sph, co
         };
         if (grid_ok)
             for (uint32_t i = 0; i < h.nlarge; ++i) { const uint32_t k = large[i]; test_large(geom[k], k); } // wave-uniform: scalar loads
-        const float dd = s.dx * s.dx + s.dy * s.dy + s.dz * s.dz;
+        const float dd = s.dxy.x * s.dxy.x + s.dxy.y * s.dxy.y + s.dz * s.dz;
         const bool unit = fabsf(dd - 1.0f) <= 1e-3f; // false for NaN/inf
         if (!grid_ok) {
             if (!fin)
@@ -542,7 +625,7 @@ __device__ __forceinline__ uint32_t trace_grid(const float *__restrict__ sph, co
                 return 1.0f / dv;
 #endif
             };
-            const float ix = recip(s.dx), iy = recip(s.dy), iz = recip(s.dz);
+            const float ix = recip(s.dxy.x), iy = recip(s.dxy.y), iz = recip(s.dz);
             auto slab = [&](float o, float dv, float inv, float lo, float hi) {
                 if (fabsf(dv) > 1e-20f) {
                     const float t1 = (lo - o) * inv, t2 = (hi - o) * inv;
@@ -550,8 +633,8 @@ __device__ __forceinline__ uint32_t trace_grid(const float *__restrict__ sph, co
                     tf = fminf(tf, fmaxf(t1, t2));
                 } else if (!(o >= lo && o <= hi)) inbox = false;
             };
-            slab(s.ox, s.dx, ix, h.gmin[0], h.gmax[0]);
-            slab(s.oy, s.dy, iy, h.gmin[1], h.gmax[1]);
+            slab(s.oxy.x, s.dxy.x, ix, h.gmin[0], h.gmax[0]);
+            slab(s.oxy.y, s.dxy.y, iy, h.gmin[1], h.gmax[1]);
             slab(s.oz, s.dz, iz, h.gmin[2], h.gmax[2]);
             if (inbox && tn <= tf) {
                 auto axis = [&](float o, float dv, float inv, float lo, float cellw, float invw, int na, int &c, int &step,
@@ -565,8 +648,8 @@ __device__ __forceinline__ uint32_t trace_grid(const float *__restrict__ sph, co
                 };
                 int c0, c1, c2, st0, st1, st2;
                 float tm0, tm1, tm2, td0, td1, td2;
-                axis(s.ox, s.dx, ix, h.gmin[0], h.cell[0], h.inv_cell[0], n0, c0, st0, tm0, td0);
-                axis(s.oy, s.dy, iy, h.gmin[1], h.cell[1], h.inv_cell[1], n1, c1, st1, tm1, td1);
+                axis(s.oxy.x, s.dxy.x, ix, h.gmin[0], h.cell[0], h.inv_cell[0], n0, c0, st0, tm0, td0);
+                axis(s.oxy.y, s.dxy.y, iy, h.gmin[1], h.cell[1], h.inv_cell[1], n1, c1, st1, tm1, td1);
                 axis(s.oz, s.dz, iz, h.gmin[2], h.cell[2], h.inv_cell[2], n2, c2, st2, tm2, td2);
                 const int max_steps = n0 + n1 + n2 + 3;
                 uint32_t cell = (uint32_t)((c2 * n1 + c1) * n0 + c0);

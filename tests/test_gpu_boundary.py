@@ -86,10 +86,12 @@ def test_contexts_render_different_sizes_from_two_threads(apt, golden, oracle):
             ctx = apt.render.Context(apt.make_params(w, h, s, depth=d))
             stream = torch.cuda.Stream()
             res = []
-            for _ in range(20):
-                colors = torch.zeros(3 * w * h * 4 * s, device="cuda")
-                ctx.render_do(8, None, stream, rays, sph, colors)
-                res.append(colors)
+            torch.cuda.synchronize()                      # rays / sph were made on the default stream
+            with torch.cuda.stream(stream):               # buffers are zeroed on the stream the render runs on
+                for _ in range(20):
+                    colors = torch.zeros(3 * w * h * 4 * s, device="cuda")
+                    ctx.render_do(8, None, stream, rays, sph, colors)
+                    res.append(colors)
             stream.synchronize()
             out[tag] = res
             ctx.close()
