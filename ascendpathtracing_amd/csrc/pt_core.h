@@ -387,8 +387,8 @@ inline void camera_init(Camera &c, uint32_t w, uint32_t h) { // gen_data.py:24-3
 #if defined(__HIP_DEVICE_COMPILE__)
 // float64 sqrt for ray-generate: the core of hipcc's own expansion (v_rsq_f64, coupled Goldschmidt
 // steps, two residual corrections) without its ldexp pre/post-scaling (only needed below 2^-767) and
-// class test (zero/inf).  Arguments here lie in {0} u [2^-53, 2]; zero or anything below 2^-700 sends
-// the wave to sqrt().  Same operations in the same order as the compiler's sequence, so the same bits
+// class test (zero/inf).  Arguments here lie in {0} u [2^-53, 2]; zero or anything below 2^-60 sends
+// the wave to sqrt() (camera_ray_t's combined test).  Same operations in the same order as the compiler's sequence, so the same bits
 // (checked against the CPU's correctly rounded sqrt by the ray tests, incl. 530 M paths of C2).
 __device__ __forceinline__ double sqrt_f64_core(double x) {
     const double y = __builtin_amdgcn_rsq(x);
@@ -401,22 +401,25 @@ __device__ __forceinline__ double sqrt_f64_core(double x) {
     d = fma(-g, g, x);
     return fma(d, h, g);
 }
-__device__ __forceinline__ double sqrt_f64_fast(double x) {
-    if (__builtin_expect(__all(x >= 0x1p-700 && x <= 0x1p700), 1)) return sqrt_f64_core(x);
-    return sqrt(x);
-}
-#define APT_SQRT64(x) sqrt_f64_fast(x)
-#else
-#define APT_SQRT64(x) sqrt(x)
 #endif
 
 // gen_data.py:37-40: dx = sqrt(r)-1 if r < 1 else 1-sqrt(2-r).  Written branch-free (one sqrt of the
 // selected argument, then the selected combination): the same operations on the same values as the
 // two-armed form, without executing both arms when the lanes of a wave disagree.
-APT_HD double tent(double u) {
+// FAST (device only): the exact fast sqrt core, valid for arguments >= 2^-60; the argument is handed back through
+// `arg` for camera_ray_t's combined validity test.
+template <bool FAST>
+APT_HD double tent_t(double u, double &arg) {
     const double r = 2 * u;
     const bool lower = r < 1;
-    const double q = APT_SQRT64(lower ? r : 2 - r);
+    const double x = lower ? r : 2 - r;
+    arg = x;
+    double q;
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (FAST) q = sqrt_f64_core(x);
+    else
+#endif
+        q = sqrt(x);
     // 1 - q is -(q - 1) bit for bit except for q == 1 (u == 0.5 exactly), where it is +0 instead of -0: the only
     // consumer adds the result to sx + 0.5 >= 0.5, which either zero leaves unchanged.
     const double t = q - 1;
@@ -440,6 +443,12 @@ __device__ __forceinline__ double div_by_rn_reciprocal(double a, double b, doubl
     const double r = fma(-b, q, a);
     return fma(r, y, q);
 }
+__device__ __forceinline__ double min3_abs_f64(double a, double b, double c) { // min(a, |b|, |c|) in two instructions, no canonicalising copies
+    double r;
+    asm("v_min_f64 %0, %1, |%2|" : "=v"(r) : "v"(a), "v"(b));
+    asm("v_min_f64 %0, %1, |%2|" : "=v"(r) : "v"(r), "v"(c));
+    return r;
+}
 __device__ __forceinline__ double refined_reciprocal(double b) {
     double y = __builtin_amdgcn_rcp(b);
     double e = fma(-b, y, 1.0);
@@ -447,57 +456,76 @@ __device__ __forceinline__ double refined_reciprocal(double b) {
     e = fma(-b, y, 1.0);
     return fma(y, e, y);
 }
-// Numerators here are bounded above by construction (|x| <= w+1 resp. |d| < 3 with u in [0,1) and a
-// finite camera), so only the lower end needs a run-time check: zero (its sign would matter), denormal or
-// absurdly small numerators send the wave to the plain '/'.  (A numerator is 0 only for a handful of
-// exact jitter values, probability ~2^-52 per path.)
-__device__ __forceinline__ bool quotient_operands_ok(double a, double b) { return fmin(fabs(a), fabs(b)) >= 0x1p-60; }
+// Validity of the fast sequences is checked ONCE per ray: `lo` = min over the two tent arguments, |xa|, |xb|,
+// |d0|, |d1|, |d2| and |d|^2 must be >= 2^-60 (nothing is zero -- its sign would matter --, denormal or absurdly
+// small: a numerator is 0 only for a handful of exact jitter values, probability ~2^-52 per path) and the norm
+// <= 2^60 (also rejects NaN / inf); everything else is bounded by construction (|x| <= w + 1, |d| < 3 with u in
+// [0, 1) and a finite camera).  If any lane of the wave fails, the whole wave recomputes the ray with sqrt() and
+// '/'.  (One combined test instead of five wave-level branches with their own compare / select / compare
+// sequences: 17 instructions per ray less.)
 #endif
+
+// Outputs are six scalar references on purpose: an aggregate result gets its stores merged into
+// vector stores to a stack slot that SROA can then no longer promote (it ended up in scratch).
+template <bool FAST>
+APT_HD bool camera_ray_t(const Camera &c, uint32_t w, uint32_t h, uint32_t i, uint32_t j, uint32_t sy, uint32_t sx,
+                         double u1, double u2, float &rox, float &roy, float &roz, float &rdx, float &rdy, float &rdz) {
+    double arg1, arg2;
+    const double ddx = tent_t<FAST>(u1, arg1), ddy = tent_t<FAST>(u2, arg2);
+    const double xa = ((double)sx + 0.5 + ddx) / 2 + (double)i, xb = ((double)sy + 0.5 + ddy) / 2 + (double)j;
+    double a, b;
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (FAST) {
+        a = div_by_rn_reciprocal(xa, (double)w, c.inv_w) - 0.5;                  // :41
+        b = div_by_rn_reciprocal(xb, (double)h, c.inv_h) - 0.5;                  // :42
+    } else
+#endif
+    {
+        a = xa / (double)w - 0.5;                                                // :41
+        b = xb / (double)h - 0.5;                                                // :42
+    }
+    // :41-43 d = cx*a + cy*b + g with the reference's camera frame, in which cx = (cx0, 0, 0), cy = (+0, cy1, cy2)
+    // and g = (+0, g1, g2) (camera_init checks it).  The vanishing terms are exact identities, signs of zero
+    // included: a = q - 0.5 is never -0, so cx0*a + (+-0) + (+0) is cx0*a bit for bit; (+-0 + cy1*b) + g1 with
+    // g1 != 0 is cy1*b + g1.  Seven float64 operations per ray less than the general form the oracle keeps.
+    const double d0 = c.cx[0] * a;
+    const double d1 = c.cy[1] * b + c.g[1];
+    const double d2 = c.cy[2] * b + c.g[2];
+    const double n2 = norm3_sq(d0, d1, d2);
+    rox = (float)(c.pos[0] + d0 * 140);                                      // :45
+    roy = (float)(c.pos[1] + d1 * 140);
+    roz = (float)(c.pos[2] + d2 * 140);
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (FAST) {
+        const double n = sqrt_f64_core(n2);
+        const double y = refined_reciprocal(n);
+        rdx = (float)div_by_rn_reciprocal(d0, n, y);                         // :46
+        rdy = (float)div_by_rn_reciprocal(d1, n, y);
+        rdz = (float)div_by_rn_reciprocal(d2, n, y);
+        double lo = min3_abs_f64(arg1, arg2, xa); // everything the fast sequences need bounded away from zero
+        lo = min3_abs_f64(lo, xb, d0);
+        lo = min3_abs_f64(lo, d1, d2);
+        asm("v_min_f64 %0, %1, %2" : "=v"(lo) : "v"(lo), "v"(n2));
+        return lo >= 0x1p-60 && n <= 0x1p60;
+    }
+#endif
+    const double n = sqrt(n2);
+    rdx = (float)(d0 / n);                                                   // :46
+    rdy = (float)(d1 / n);
+    rdz = (float)(d2 / n);
+    return true;
+}
 
 // Outputs are six scalar references on purpose: an aggregate result gets its stores merged into
 // vector stores to a stack slot that SROA can then no longer promote (it ended up in scratch).
 APT_HD void camera_ray(const Camera &c, uint32_t w, uint32_t h, uint32_t i, uint32_t j, uint32_t sy, uint32_t sx,
                        double u1, double u2, float &rox, float &roy, float &roz, float &rdx, float &rdy, float &rdz) {
-    double ddx = tent(u1), ddy = tent(u2);
-    const double xa = ((double)sx + 0.5 + ddx) / 2 + (double)i, xb = ((double)sy + 0.5 + ddy) / 2 + (double)j;
 #if defined(__HIP_DEVICE_COMPILE__)
-    const bool ok1 = quotient_operands_ok(xa, xb);
-    double a, b;
-    if (__builtin_expect(__all(ok1), 1)) {
-        a = div_by_rn_reciprocal(xa, (double)w, c.inv_w) - 0.5;                  // :41
-        b = div_by_rn_reciprocal(xb, (double)h, c.inv_h) - 0.5;                  // :42
-    } else {
-        a = xa / (double)w - 0.5;
-        b = xb / (double)h - 0.5;
-    }
-#else
-    double a = xa / (double)w - 0.5;                                             // :41
-    double b = xb / (double)h - 0.5;                                             // :42
+    const bool ok = camera_ray_t<true>(c, w, h, i, j, sy, sx, u1, u2, rox, roy, roz, rdx, rdy, rdz);
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(!ok) == 0, 1)) return;
+    asm volatile("" ::: "memory"); // keeps the exact form out of the hot path's schedule
 #endif
-    // :41-43 d = cx*a + cy*b + g with the reference's camera frame, in which cx = (cx0, 0, 0), cy = (+0, cy1, cy2)
-    // and g = (+0, g1, g2) (camera_init checks it).  The vanishing terms are exact identities, signs of zero
-    // included: a = q - 0.5 is never -0, so cx0*a + (+-0) + (+0) is cx0*a bit for bit; (+-0 + cy1*b) + g1 with
-    // g1 != 0 is cy1*b + g1.  Seven float64 operations per ray less than the general form the oracle keeps.
-    double d0 = c.cx[0] * a;
-    double d1 = c.cy[1] * b + c.g[1];
-    double d2 = c.cy[2] * b + c.g[2];
-    double n = APT_SQRT64(norm3_sq(d0, d1, d2));
-    rox = (float)(c.pos[0] + d0 * 140);                                      // :45
-    roy = (float)(c.pos[1] + d1 * 140);
-    roz = (float)(c.pos[2] + d2 * 140);
-#if defined(__HIP_DEVICE_COMPILE__)
-    const bool ok2 = quotient_operands_ok(fmin(fabs(d0), fabs(d1)), d2) && n <= 0x1p60; // n >= max|d_i| >= 2^-60; n <= 2^60 also rejects NaN/inf
-    if (__builtin_expect(__all(ok2), 1)) {
-        const double y = refined_reciprocal(n);
-        rdx = (float)div_by_rn_reciprocal(d0, n, y);                         // :46
-        rdy = (float)div_by_rn_reciprocal(d1, n, y);
-        rdz = (float)div_by_rn_reciprocal(d2, n, y);
-        return;
-    }
-#endif
-    rdx = (float)(d0 / n);                                                   // :46
-    rdy = (float)(d1 / n);
-    rdz = (float)(d2 / n);
+    (void)camera_ray_t<false>(c, w, h, i, j, sy, sx, u1, u2, rox, roy, roz, rdx, rdy, rdz);
 }
 APT_HD Ray camera_ray(const Camera &c, uint32_t w, uint32_t h, uint32_t i, uint32_t j, uint32_t sy, uint32_t sx,
                       double u1, double u2) {

@@ -200,7 +200,8 @@ __device__ __forceinline__ void apply_albedo(f2 &rxy, float &rz, const Albedo &a
                  "v_mul_f32 %[rz], %[cz], %[rz]\n\t"
                  "s_mov_b64 exec, %[sv]"
                  : [sv] "=&s"(saved), [rxy] "+v"(rxy), [rz] "+v"(rz)
-                 : [m] "s"(alive), [cxy] "v"(a.xy), [cz] "v"(a.z));
+                 : [m] "s"(alive), [cxy] "v"(a.xy), [cz] "v"(a.z)
+                 : "scc");   // s_and_saveexec writes SCC: the compiler must not keep a scalar compare alive across this
 }
 
 template <int MODE>
@@ -337,7 +338,7 @@ __device__ __forceinline__ uint64_t bounce_ns8_v2(const Scene8 &sc, const Tab8 t
     n.alive = s.alive;
     albedo = Albedo{f2{col.x, col.y}, col.z};
     const uint64_t tiny = __builtin_amdgcn_ballot_w64(amin < 0x1p-96f);
-    const uint64_t huge = __builtin_amdgcn_ballot_w64((int32_t)(0x5d800000u - f32_bits(len2)) < 0); // len2 > 2^60 (or NaN): see div3_shared
+    const uint64_t huge = __builtin_amdgcn_ballot_w64(f32_bits(len2) > 0x5d800000u); // len2 > 2^60 or NaN (len2 is never negative): see div3_shared
     return tiny | huge;
 }
 
