@@ -7,10 +7,13 @@
 // (main.cpp:72 copies them over the rays -- the "all black" bug of problem.md:41).
 //
 //   render_gpu [--width W] [--height H] [--samples S] [--depth D] [--spheres Ns]
-//              [--mode k|o] [--retire] [--frame] [--seed X]
+//              [--mode k|o] [--retire] [--frame] [--seed X] [--gpus N] [--stripes K]
 // With no options it behaves like the reference binary: 16x16, S=1, depth 5, 8 spheres.
 // --frame runs the fused device path instead (rays generated on the device, samples
-// accumulated on the device) and writes ./output/color.ppm directly.
+// accumulated on the device) and writes ./output/color.ppm directly.  With --gpus N (> 1, implies --frame) the
+// frame is sharded over N devices in this ONE process (apt_multi_*: band d on device d, the reference's
+// contiguous split of src/render.cpp:9-10,24-27; --stripes K interleaves K stripes per device) and assembled on
+// device 0 by peer copies; per-band kernel times are printed.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -60,6 +63,7 @@ int main(int argc, char **argv) {
     apt_render_params prm;
     apt_default_params(&prm);
     bool frame = false;
+    int gpus = 1, stripes = 1;
     for (int i = 1; i < argc; ++i) {
         const std::string a = argv[i];
         auto val = [&]() -> const char * { if (i + 1 >= argc) { fprintf(stderr, "missing value for %s\n", a.c_str()); exit(1); } return argv[++i]; };
@@ -72,6 +76,8 @@ int main(int argc, char **argv) {
         else if (a == "--seed") prm.seed = strtoull(val(), nullptr, 0);
         else if (a == "--retire") prm.flags |= APT_FLAG_RETIRE;
         else if (a == "--frame") frame = true;
+        else if (a == "--gpus") { gpus = atoi(val()); frame = true; }
+        else if (a == "--stripes") stripes = atoi(val());
         else { fprintf(stderr, "unknown option %s\n", a.c_str()); return 1; }
     }
     if (apt_device_count() < 1) { fprintf(stderr, "[ERROR]  no HIP device: the GPU path cannot run here\n"); return 2; }
@@ -93,7 +99,25 @@ int main(int argc, char **argv) {
     CHECK_HIP(hipMalloc(&sphDev, sphBytes));
     CHECK_HIP(hipMemcpyAsync(sphDev, sphHost.data(), sphBytes, hipMemcpyHostToDevice, stream));
 
-    if (frame) {
+    if (frame && gpus > 1) {
+        if (gpus > apt_device_count() || stripes < 1) { fprintf(stderr, "[ERROR]  --gpus %d: only %d device(s) visible\n", gpus, apt_device_count()); return 2; }
+        const size_t npix = (size_t)prm.width * prm.height;
+        std::vector<int> ids(gpus);
+        for (int d = 0; d < gpus; ++d) ids[d] = d;
+        apt_multi *mg = nullptr;
+        if (apt_multi_create(ids.data(), (uint32_t)gpus, (uint32_t)stripes, &prm, sphHost.data(), &mg) != APT_OK) { fprintf(stderr, "[ERROR]  %s\n", apt_last_error()); return 4; }
+        float *fbDev = nullptr; uint8_t *u8Dev = nullptr;
+        CHECK_HIP(hipMalloc(&fbDev, npix * 3 * sizeof(float)));
+        CHECK_HIP(hipMalloc(&u8Dev, npix * 3));
+        std::vector<float> band_ms(gpus);
+        if (apt_multi_render(mg, fbDev, u8Dev, band_ms.data()) != APT_OK) { fprintf(stderr, "[ERROR]  %s\n", apt_last_error()); return 4; }
+        for (int d = 0; d < gpus; ++d) printf("[INFO]  device %d band kernel %.3f ms\n", d, band_ms[d]);
+        std::vector<uint8_t> u8(npix * 3);
+        CHECK_HIP(hipMemcpy(u8.data(), u8Dev, u8.size(), hipMemcpyDeviceToHost));
+        if (apt_write_ppm("./output/color.ppm", prm.width, prm.height, u8.data()) != APT_OK) return 5;
+        apt_multi_destroy(mg);
+        CHECK_HIP(hipFree(fbDev)); CHECK_HIP(hipFree(u8Dev));
+    } else if (frame) {
         const size_t npix = (size_t)prm.width * prm.height;
         float *fbDev = nullptr; uint8_t *u8Dev = nullptr;
         CHECK_HIP(hipMalloc(&fbDev, npix * 3 * sizeof(float)));
@@ -113,7 +137,7 @@ int main(int argc, char **argv) {
         CHECK_HIP(hipMemcpyAsync(rayDev, rayHost.data(), rayBytes, hipMemcpyHostToDevice, stream)); // main.cpp:69
         if (apt_set_default_params(&prm) != APT_OK) { fprintf(stderr, "[ERROR]  %s\n", apt_last_error()); return 4; }
         render_do(blockDim, nullptr, stream, (uint8_t *)rayDev, (uint8_t *)sphDev, (uint8_t *)colDev); // main.cpp:74
-        if (apt_last_error()[0]) { fprintf(stderr, "[ERROR]  %s\n", apt_last_error()); return 4; }
+        if (apt_last_status() != APT_OK) { fprintf(stderr, "[ERROR]  %s\n", apt_last_error()); return 4; }
         CHECK_HIP(hipStreamSynchronize(stream));                              // main.cpp:75
         CHECK_HIP(hipMemcpy(colHost.data(), colDev, colBytes, hipMemcpyDeviceToHost)); // main.cpp:77
         if (!write_file("./output/color.bin", colHost.data(), colBytes)) return 5;     // main.cpp:79

@@ -1,21 +1,26 @@
 #!/usr/bin/env python3
-"""bench.py -- the reference's headline metric on MI355X: Mray/s on the demo scene at
-1920x1080, 8 bounces, 256 spp (BASELINE.json configs[1], "C2").
+"""bench.py -- the reference's headline metric on MI355X: Mray/s (ray segments per second).
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-One "step" = one full frame through the hot path on every rank: rays generated on the
-device, all N*D ray segments traced, 4*S samples per pixel accumulated on the device, and
-(N > 1) the framebuffer slices gathered to rank 0 over RCCL (asynchronously, double-buffered: the
-gather of frame k overlaps the render of frame k+1; all gathers are finished inside the timed region).  Nothing is retired or
-skipped in the timed kernel (APT_FLAG_RETIRE off): every one of the W*H*4*S*D segments is
-traced, like the reference does.  Inputs (the 512-byte scene) are resident in HBM before
-the timed region.  Weak scaling: each rank owns a 1920-column band of a (1920*N)x1080 image.
+One "step" = one full frame through the hot path: rays generated on the device, every one of the
+W*H*4*S*D segments traced (APT_FLAG_RETIRE off, like the reference), 4*S samples per pixel accumulated on the
+device, and (N > 1) the framebuffer bands gathered to rank 0 over RCCL (asynchronously, double-buffered: the
+gather of frame k overlaps the render of frame k+1; all gathers are finished inside the timed region).  Inputs
+(the 512-byte scene) are resident in HBM before the timed region.
 
-The JSON line carries `roofline` (fp32 VALU bound: SURVEY.md 8(d), F(Ns)=20*Ns+33 fp32
-operations per segment) and, at N=1 on rank 0, `cpu_baseline` (the oracle's C restatement
-timed on the host cores on a bounded pixel sample of the same workload).
+Workload (BASELINE.json `configs`):
+    N = 1   configs[1] "C2": 1920x1080, 256 spp (S=64), 8 bounces, demo scene -- the configuration the metric is quoted on
+    N > 1   configs[2] "C3": 4096x4096, 1024 spp (S=256), 8 bounces, strong-sharded: rank r renders the contiguous pixel
+            band dist.split_range gives it (the reference's own split, src/render.cpp:9-10,24-27), one RCCL gather.
+            `scaling` is "strong" (total work fixed); `value` stays a rate (segments/s of the whole job), so the per-N
+            values are directly comparable with the N = 1 line.  (--workload c2-weak: one C2 band per rank instead.)
+
+The JSON line carries `roofline` (VALU-issue bound: SURVEY.md 8(d), F(Ns)=20*Ns+33 fp32 operations per segment against
+the vector fp32 peak) and, at N=1 on rank 0, `cpu_baseline` (the oracle's C restatement timed on the host cores on a
+bounded pixel sample of the same workload) plus `extra` (the same frame in O-mode, with compaction, and through the
+reference's exact MT19937 pipeline).
 """
 import argparse
 import json
@@ -26,7 +31,9 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-W, H, S, D, NS = 1920, 1080, 64, 8, 8
+NS = 8
+C2 = dict(name="C2", w=1920, h=1080, s=64, depth=8)
+C3 = dict(name="C3", w=4096, h=4096, s=256, depth=8)
 PEAK_FP32_TFLOPS = 157.3                      # MI355X_MICROARCH.md: vector fp32 (== f32 MFMA) peak, FMA counted as 2
 PEAK_NOFMA_TOPS = 78.6                        # same lanes with FMA forbidden by bit-parity
 MEASURED_NOFMA_TOPS = 68.6                    # v_pk_add/mul_f32 issue rate measured on MI355X (profiles/microbench/valu_rates_mi355x.txt)
@@ -59,11 +66,22 @@ def effective_cpus():
     return n
 
 
-def cpu_baseline(budget_s=12.0):
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(cfg, budget_s=12.0):
     """The oracle (kind "port": the reference's own CPU path needs Huawei CANN and cannot be
-    built) on all host threads, on as many 4096-pixel chunks of the C2 frame as fit in
+    built) on all host threads, on as many 4096-pixel chunks of the frame as fit in
     ~budget_s seconds.  Checker code: imported here only to be TIMED as the baseline."""
     from oracle import oracle
+    W, H, S, D = cfg["w"], cfg["h"], cfg["s"], cfg["depth"]
     threads = min(oracle.max_threads(), effective_cpus())
     sph = oracle.gen_spheres()
     p = oracle.make_params(W, H, S, depth=D, num_spheres=NS, mode=oracle.MODE_K, seed=0)
@@ -89,17 +107,19 @@ def cpu_baseline(budget_s=12.0):
 
     by_threads = {"1": short_run(1, 2.0), "8": short_run(min(8, threads), 2.0)}
     return {"value": round(seg / dt / 1e6, 3), "unit": "Mray/s", "cores": threads, "kind": "port", "by_threads": by_threads,
+            "cpu_model": cpu_model(), "host_threads_visible": os.cpu_count(),
             "sample": f"{done} pixels of the {W}x{H} frame x {4 * S} spp x {D} bounces = {seg} segments in {dt:.1f} s "
                       f"(K-mode C restatement, gcc -O2 -ffp-contract=off, OpenMP)"}
 
 
-def quality_check(frame, pixels=2048):
+def quality_check(cfg, fb, u8, pixels=2048):
     """BASELINE quality metric on a strided sample of the frame just rendered: per-channel RMS between
     the GPU's and the CPU restatement's float pixel values (after mean + clip, range [0,1]) and the
     number of differing 8-bit PPM values.  Target <= 1e-4; the GPU path is bit-identical, so 0."""
     import numpy as np
     from oracle import oracle
-    fb, u8 = frame[0].cpu().numpy(), frame[1].cpu().numpy()
+    W, H, S, D = cfg["w"], cfg["h"], cfg["s"], cfg["depth"]
+    fb, u8 = fb.cpu().numpy(), u8.cpu().numpy()
     sph = oracle.gen_spheres()
     p = oracle.make_params(W, H, S, depth=D, num_spheres=NS, mode=oracle.MODE_K, seed=0)
     run, npix = 16, W * H
@@ -115,14 +135,63 @@ def quality_check(frame, pixels=2048):
             "reference": "oracle C restatement, K-mode", "target_rms": 1e-4}
 
 
+def timed(torch, fn, reps):
+    fn(); torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    for a, b in ev:
+        a.record(); fn(); b.record()
+    torch.cuda.synchronize()
+    return sum(a.elapsed_time(b) for a, b in ev) / len(ev)
+
+
+def extras(torch, apt, render, gen_data, cfg, sph, steps):
+    """N = 1 only, after the timed region: the same C2 frame (a) in O-mode (the NumPy oracle's arithmetic), (b) with
+    result-preserving retirement + wave-queue compaction, (c) through the reference's exact pipeline on the device
+    (MT19937 gen_rays -> buffer-mode render in O-mode -> decode_color; 19 GB of intermediates)."""
+    W, H, S, D = cfg["w"], cfg["h"], cfg["s"], cfg["depth"]
+    out = {}
+    po = apt.make_params(W, H, S, depth=D, mode=apt.APT_MODE_ORACLE)
+    out["c2_o_mode_kernel_ms"] = round(timed(torch, lambda: render.render_frame(po, sph), steps), 3)
+    pr = apt.make_params(W, H, S, depth=D, flags=apt.APT_FLAG_RETIRE)
+    rms = timed(torch, lambda: render.render_frame(pr, sph), steps)
+    with render.TraceCounter() as tc:       # counted in a separate, untimed launch (the counter's atomics are slow)
+        render.render_frame(pr, sph)
+    nominal = W * H * 4 * S * D
+    out["c2_retire"] = {"kernel_ms": round(rms, 3), "traced_segments": tc.value, "nominal_segments": nominal,
+                        "nominal_mray_per_s": round(nominal / rms / 1e3, 1), "traced_mray_per_s": round(tc.value / rms / 1e3, 1)}
+    try:
+        t0 = time.time()
+        ck = torch.from_numpy(gen_data.mt19937_checkpoints(W * H * 4 * S, seed=0, stride=64).view("int32")).cuda()
+        t_ck = time.time() - t0
+        rays = gen_data.gen_rays_device(W, H, S, checkpoints=ck, stride=64).reshape(-1)
+        colors = torch.empty(3 * po.num_paths, device="cuda")
+        ms_gen = timed(torch, lambda: gen_data.gen_rays_device(W, H, S, checkpoints=ck, stride=64), 2)
+        ms_ren = timed(torch, lambda: render.render_do_ex(po, None, rays, sph, colors), 2)
+        ms_dec = timed(torch, lambda: render.decode_color_device(po, colors), 2)
+        out["c2_exact_reference_pipeline"] = {"total_ms": round(ms_gen + ms_ren + ms_dec, 3), "gen_rays_mt19937_ms": round(ms_gen, 3),
+                                              "render_o_mode_buffer_ms": round(ms_ren, 3), "decode_color_ms": round(ms_dec, 3),
+                                              "host_checkpoint_seconds_once": round(t_ck, 2), "hbm_gb_resident": round(36 * po.num_paths / 1e9, 1)}
+        del rays, colors, ck
+        torch.cuda.empty_cache()
+    except Exception as e:                   # noqa: BLE001  (an extra must never cost the headline line)
+        out["c2_exact_reference_pipeline"] = {"error": repr(e)[:200]}
+    return out
+
+
 def main():
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # before anything initialises HIP (dmabuf IPC only on this pool)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", choices=["auto", "c2", "c3", "c2-weak"], default="auto")
+    ap.add_argument("--stripes", type=int, default=1, help="interleaved stripes per rank (N > 1; see dist.py)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--retire", action="store_true", help="also time the frame with APT_FLAG_RETIRE (extra field)")
+    ap.add_argument("--no-extra", action="store_true")
     args = ap.parse_args()
+
+    import __graft_entry__
+    __graft_entry__.build()                   # incremental, serialised by a file lock; does not touch the GPU
 
     import torch
     import torch.distributed as dist
@@ -137,27 +206,31 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus} "
                          f"(WORLD_SIZE is {world})")
     apt._lib.require_gpu()
-    local_rank %= max(torch.cuda.device_count(), 1)
+    ndev = torch.cuda.device_count()
+    if local_rank >= ndev:
+        raise SystemExit(f"LOCAL_RANK {local_rank} but only {ndev} GPU(s) visible: one process per GPU, no sharing")
     torch.cuda.set_device(local_rank)
     if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    # weak scaling: the image grows by one 1920-column band per rank (x-major pixel index, so a
-    # band of columns is a contiguous pixel range: SURVEY.md 8(e))
-    width = W * world
-    p = apt.make_params(width, H, S, depth=D, num_spheres=NS, mode=apt.APT_MODE_KERNEL, seed=0)
+    workload = args.workload
+    if workload == "auto":
+        workload = "c2" if world == 1 else "c3"
+    cfg = dict(C3 if workload == "c3" else C2)
+    if workload == "c2-weak":                  # the image grows by one 1920-column band per rank (x-major pixel index:
+        cfg["w"] = cfg["w"] * world            # a band of columns is a contiguous pixel range)
+    W, H, S, D = cfg["w"], cfg["h"], cfg["s"], cfg["depth"]
+    p = apt.make_params(W, H, S, depth=D, num_spheres=NS, mode=apt.APT_MODE_KERNEL, seed=0)
     sph = torch.from_numpy(gen_data.gen_spheres()).cuda()
     # two packed slots: the RCCL gather of frame k overlaps the render of frame k+1 (separate streams)
-    shard = apt_dist.FrameShard(p, rank, world, slots=2)
+    shard = apt_dist.FrameShard(p, rank, world, slots=2, stripes=args.stripes if world > 1 else 1)
     slots = shard.alloc_slots()
     full = shard.alloc_full() if rank == 0 else (None, None)
 
     def step(k, events=None):
-        fb, u8 = slots[k % 2]
         if events:
-            events[0].record()                # torch's current stream == the stream the kernel is launched on
-        render.render_frame(p, sph, shard.pixel_begin, shard.pixel_count, fb=fb, fb_u8=u8)
+            events[0].record()                # torch's current stream == the stream the kernels are launched on
+        shard.render(slots[k % 2], sph, render.render_frame)
         if events:
             events[1].record()
         if world > 1:
@@ -178,56 +251,60 @@ def main():
         step(k, e)
     sync()
     dt = time.perf_counter() - t0
-    kern_ms = sum(a.elapsed_time(b) for a, b in ev) / len(ev)     # HIP events around each launch
+    kern_ms = sum(a.elapsed_time(b) for a, b in ev) / len(ev)     # HIP events around this rank's launch(es)
 
+    per_rank_ms = [kern_ms]
     if world > 1:
         t = torch.tensor([dt, kern_ms], dtype=torch.float64, device="cuda")
+        allk = [torch.zeros(1, dtype=torch.float64, device="cuda") for _ in range(world)]
+        dist.all_gather(allk, t[1:2].clone())
+        per_rank_ms = [float(x) for x in allk]
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt, kern_ms = float(t[0]), float(t[1])
 
-    seg_per_rank = shard.pixel_count * 4 * S * D
-    seg_total = seg_per_rank * world
+    seg_rank = shard.pixel_count * 4 * S * D
+    seg_total = W * H * 4 * S * D
     ms_per_step = dt / args.steps * 1e3
     value = seg_total / (dt / args.steps) / 1e6
-    achieved = seg_per_rank * flops_per_segment(NS) / (kern_ms * 1e-3) / 1e12
+    achieved = seg_rank * flops_per_segment(NS) / (kern_ms * 1e-3) / 1e12
+    traffic, traffic_tag = apt_dist.recorded_traffic(ROOT)
+    if workload != "c2" or world != 1:
+        traffic, traffic_tag = None, None     # the committed PMC passes are of the N = 1 C2 launch
+    names = {"c2": f"C2: gen_spheres() 8-sphere scene, {W}x{H}, S={S} ({4 * S} spp), depth {D}",
+             "c3": f"C3: gen_spheres() 8-sphere scene, {W}x{H}, S={S} ({4 * S} spp), depth {D}, strong-sharded over {world} rank(s): "
+                   f"contiguous pixel bands (dist.split_range), {shard.pixel_count} pixels per rank",
+             "c2-weak": f"C2 weak scaling: one 1920x{H} band per rank ({W}x{H} total), S={S}, depth {D}"}
     out = {
         "metric": "Mray/s (ray segments per second) at 1080p, 8 bounces, 256 spp, demo scene",
         "value": round(value, 1), "unit": "Mray/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
+        "scaling": "weak" if workload == "c2-weak" or world == 1 else "strong", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"C2: gen_spheres() 8-sphere scene, {W}x{H} per GPU ({width}x{H} total), "
-                               f"S={S} (256 spp), depth {D}, rays generated on device (counter RNG, seed 0), "
-                               f"K-mode arithmetic, all segments traced (no retirement)",
-                   "paths_per_gpu": shard.pixel_count * 4 * S, "segments_per_gpu": seg_per_rank,
-                   "parallelism": f"pixel-column bands x{world}, one RCCL gather" if world > 1 else "single GPU"},
+        "config": {"workload": names[workload] + ", rays generated on device (counter RNG, seed 0), K-mode arithmetic, "
+                               "all segments traced (no retirement)",
+                   "paths_per_gpu": shard.pixel_count * 4 * S, "segments_per_gpu": seg_rank, "segments_per_step": seg_total,
+                   "parallelism": (f"pixel bands x{world} ({shard.stripes} stripe(s) per rank), one RCCL gather to rank 0, "
+                                   f"double-buffered") if world > 1 else "single GPU"},
         "roofline": {"bound": "valu", "kernel": "render_frame_kernel<K,ns8,group8>", "achieved": round(achieved, 3),
                      "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_TFLOPS, 4),
                      "frac_of_nofma_peak": round(achieved / PEAK_NOFMA_TOPS, 4),
                      "frac_of_measured_nofma_ceiling": round(achieved / MEASURED_NOFMA_TOPS, 4),
                      "flops_per_segment": flops_per_segment(NS), "kernel_ms": round(kern_ms, 3),
-                     "traffic": apt_dist.recorded_traffic(ROOT)},
+                     "traffic": traffic, "traffic_recorded_for_build": traffic_tag},
         "target_mray_per_gpu": 100.0,
     }
-    if args.retire:   # same frame with result-preserving retirement + wave-queue compaction (bit-identical image)
-        pr = p.copy(flags=apt.APT_FLAG_RETIRE)
-        for _ in range(2):
-            render.render_frame(pr, sph, shard.pixel_begin, shard.pixel_count, fb=slots[0][0], fb_u8=slots[0][1])
-        torch.cuda.synchronize()
-        evr = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-        for a, b in evr:
-            a.record()
-            render.render_frame(pr, sph, shard.pixel_begin, shard.pixel_count, fb=slots[0][0], fb_u8=slots[0][1])
-            b.record()
-        torch.cuda.synchronize()
-        rms = sum(a.elapsed_time(b) for a, b in evr) / len(evr)
-        with render.TraceCounter() as tc:       # counted in a separate, untimed launch (the counter's atomics are slow)
-            render.render_frame(pr, sph, shard.pixel_begin, shard.pixel_count, fb=slots[0][0], fb_u8=slots[0][1])
-        out["retire"] = {"kernel_ms": round(rms, 3), "traced_segments": tc.value, "nominal_segments": seg_per_rank,
-                         "nominal_mray_per_s": round(seg_per_rank / rms / 1e3, 1),
-                         "traced_mray_per_s": round(tc.value / rms / 1e3, 1)}
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["quality"] = quality_check(slots[(args.steps - 1) % 2])
-        out["cpu_baseline"] = cpu_baseline()
+    if world > 1:       # strong scaling: the frame takes max(band kernel) + whatever the gather / sync leaves uncovered
+        out["ranks"] = {"kernel_ms_per_rank": [round(x, 3) for x in per_rank_ms],
+                        "slowest_band_kernel_ms": round(max(per_rank_ms), 3),
+                        "uncovered_gather_and_sync_ms_per_step": round(ms_per_step - max(per_rank_ms), 3),
+                        "load_imbalance_max_over_mean": round(max(per_rank_ms) / (sum(per_rank_ms) / world), 4)}
+    if rank == 0 and world == 1:
+        if not args.no_cpu_baseline:
+            fbv, u8v = slots[(args.steps - 1) % 2][0]
+            out["quality"] = quality_check(cfg, fbv, u8v)
+            out["cpu_baseline"] = cpu_baseline(cfg)
+        if not args.no_extra and workload == "c2":
+            out["extra"] = extras(torch, apt, render, gen_data, cfg, sph, max(3, args.steps // 2))
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

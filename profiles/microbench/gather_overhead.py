@@ -15,12 +15,12 @@ shard = apt_dist.FrameShard(p, 0, 1, slots=2)
 slots = shard.alloc_slots(); full = shard.alloc_full()
 def run(gather, n=20):
     for k in range(3):
-        render.render_frame(p, sph, 0, shard.pixel_count, fb=slots[k % 2][0], fb_u8=slots[k % 2][1])
+        shard.render(slots[k % 2], sph, render.render_frame)
         if gather: shard.gather_async(k % 2, *full)
     shard.finish(); torch.cuda.synchronize()
     t0 = time.perf_counter()
     for k in range(n):
-        render.render_frame(p, sph, 0, shard.pixel_count, fb=slots[k % 2][0], fb_u8=slots[k % 2][1])
+        shard.render(slots[k % 2], sph, render.render_frame)
         if gather: shard.gather_async(k % 2, *full)
     shard.finish(); torch.cuda.synchronize()
     return (time.perf_counter() - t0) / n * 1e3

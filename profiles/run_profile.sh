@@ -4,12 +4,12 @@
 # Pass 1: --kernel-trace --stats (per-kernel durations).  Passes 2..: --pmc only, one counter
 # group per pass (never combined with tracing domains other than kernel-trace).
 set -u
-TAG=${1:-r01}
+TAG=${1:-r02}
 OUT=gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd "$(dirname "$0")/.." || exit 1
 export TMPDIR=/tmp
-CMD="python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline"
+CMD="python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extra"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- $CMD > "$OUT/trace.log" 2>&1 || echo "trace pass failed"
 rocprofv3 -L > "$OUT/counters_available.txt" 2>&1 || true
 i=0
