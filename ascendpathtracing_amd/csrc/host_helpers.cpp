@@ -154,20 +154,33 @@ int apt_gen_rays_host(uint32_t width, uint32_t height, uint32_t samples, uint32_
 // block b (624 words = the 4 words of 156 consecutive paths) is the tempering of the state after
 // b+1 twists; checkpoint i is that raw state for block i*stride.  Sequential by nature; done once
 // per (seed, length) and reusable for every shorter length.
-int apt_mt19937_checkpoints_host(uint32_t seed, uint64_t num_blocks, uint32_t stride, uint32_t *states) {
+int apt_mt19937_checkpoints_window(const uint32_t *state_in, uint32_t seed, uint64_t first_block, uint64_t num_blocks,
+                                   uint32_t stride, uint32_t *states, uint32_t *state_out) {
     apt::clear_error();
-    if (!states || stride == 0 || num_blocks == 0) return set_error(APT_ERR_ARG, "apt_mt19937_checkpoints_host: states must be non-null, stride and num_blocks non-zero%s");
+    if (!states || stride == 0 || num_blocks == 0) return set_error(APT_ERR_ARG, "apt_mt19937_checkpoints_window: states must be non-null, stride and num_blocks non-zero%s");
     uint32_t mt[624];
-    mt[0] = seed;
-    for (int i = 1; i < 624; ++i) mt[i] = 1812433253u * (mt[i - 1] ^ (mt[i - 1] >> 30)) + (uint32_t)i;
-    for (uint64_t b = 0; b < num_blocks; ++b) {
-        for (int i = 0; i < 624; ++i) { // genrand twist
+    auto twist = [&]() { // genrand twist
+        for (int i = 0; i < 624; ++i) {
             const uint32_t y = (mt[i] & 0x80000000u) | (mt[(i + 1) % 624] & 0x7fffffffu);
             mt[i] = mt[(i + 397) % 624] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
         }
-        if (b % stride == 0) memcpy(states + (b / stride) * 624, mt, sizeof mt);
+    };
+    if (state_in) memcpy(mt, state_in, sizeof mt);
+    else {
+        mt[0] = seed;
+        for (int i = 1; i < 624; ++i) mt[i] = 1812433253u * (mt[i - 1] ^ (mt[i - 1] >> 30)) + (uint32_t)i;
+        for (uint64_t b = 0; b <= first_block; ++b) twist(); // block b is the tempering of the state after b+1 twists
     }
+    for (uint64_t k = 0; k < num_blocks; ++k) {               // mt = raw state of block first_block + k
+        if (k % stride == 0) memcpy(states + (k / stride) * 624, mt, sizeof mt);
+        if (k + 1 < num_blocks || state_out) twist();
+    }
+    if (state_out) memcpy(state_out, mt, sizeof mt);
     return APT_OK;
+}
+
+int apt_mt19937_checkpoints_host(uint32_t seed, uint64_t num_blocks, uint32_t stride, uint32_t *states) {
+    return apt_mt19937_checkpoints_window(nullptr, seed, 0, num_blocks, stride, states, nullptr);
 }
 
 int apt_gen_spheres_host(float *spheres128) {

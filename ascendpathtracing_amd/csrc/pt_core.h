@@ -166,6 +166,35 @@ __device__ __forceinline__ void div3_shared(float nx, float ny, float nz, float 
     uz = __builtin_fmaf(e, r, q);
 }
 
+
+#endif
+
+#if defined(__HIPCC__) // device functions that host-pass code in pt_trace.h / pt_kernels.h names
+// The same three quotients with x and y in one register pair (v_pk_mul_f32 / v_pk_fma_f32 round each half exactly
+// like the scalar instructions): the form the 8-sphere bounce block uses.  Validity is the caller's business:
+// div3_operands_ok() below states it, the bounce block evaluates the same conditions with two v_min3_f32 and two
+// compares for the whole wave, and apt_selftest_div3 checks this function under exactly that predicate.
+typedef float f2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void div3_packed(f2_t nxy, float nz, float d, f2_t &uxy, float &uz) {
+    const float r0 = __builtin_amdgcn_rcpf(d);
+    const float e0 = __builtin_fmaf(-d, r0, 1.0f);
+    const float r = __builtin_fmaf(e0, r0, r0);
+    const f2_t nd = {-d, -d}, rr = {r, r};
+    f2_t q2 = nxy * r;
+    f2_t e2 = __builtin_elementwise_fma(nd, q2, nxy);
+    q2 = __builtin_elementwise_fma(e2, rr, q2);
+    e2 = __builtin_elementwise_fma(nd, q2, nxy);
+    uxy = __builtin_elementwise_fma(e2, rr, q2);
+    float q = nz * r, e = __builtin_fmaf(-d, q, nz);
+    q = __builtin_fmaf(e, r, q);
+    e = __builtin_fmaf(-d, q, nz);
+    uz = __builtin_fmaf(e, r, q);
+}
+// |numerators| and len2 >= 2^-96 (not -0, no scaling needed), len2 <= 2^60 and not NaN (d = sqrt(len2) <= 2^30).
+__device__ __forceinline__ bool div3_operands_ok(float len2, float nx, float ny, float nz) {
+    const float lo = fminf(fminf(fabsf(nx), fabsf(ny)), fminf(fabsf(nz), len2));
+    return lo >= 0x1p-96f && !(__float_as_uint(len2) > 0x5d800000u);
+}
 #endif
 
 // The two roots b -/+ q of one ray/sphere pair; FAST uses sqrt_rn_rsq1 on the device.

@@ -114,7 +114,7 @@ struct FrameArgs {
 // a 3-step butterfly and no shared memory.  GROUP == 1 serves samples < 8 (numpy sums
 // those sequentially).
 template <int MODE, int SC, int GROUP, bool RETIRE>
-__global__ __launch_bounds__(kBlock, (RETIRE && SC == kScene8 && GROUP == 8) ? 5 : (SC == kSceneGrid ? APT_GRID_WAVES : APT_FULL_WAVES)) void render_frame_kernel(const float *__restrict__ sph, FrameArgs fa,
+__global__ __launch_bounds__(kBlock, (RETIRE && SC == kScene8 && GROUP == 8) ? 4 : (SC == kSceneGrid ? APT_GRID_WAVES : APT_FULL_WAVES)) void render_frame_kernel(const float *__restrict__ sph, FrameArgs fa,
                                                               TraceArgs ta, LeafProg lp) {
     constexpr bool NS8 = SC == kScene8;
     __shared__ float4 tab[16];
@@ -404,12 +404,12 @@ __device__ __forceinline__ uint32_t mt_temper(uint32_t y) {
 constexpr int kMtGroup = 8; // output blocks tempered into LDS before the rays of their 8*156 paths are made
 
 __global__ __launch_bounds__(kBlock) void gen_rays_mt_kernel(const uint32_t *__restrict__ checkpoints, uint32_t stride,
-                                                             uint64_t num_blocks, Camera cam, uint32_t width,
+                                                             uint64_t first_block, uint64_t num_blocks, Camera cam, uint32_t width,
                                                              uint32_t height, uint32_t samples, uint64_t n_total,
                                                              uint64_t begin, uint64_t end, float *__restrict__ rays) {
     __shared__ uint32_t mt[kMtN];
     __shared__ __align__(16) uint32_t outw[kMtGroup * kMtN]; // tempered output words of up to kMtGroup consecutive blocks (20 KB); read back as uint4
-    const uint64_t cb = (uint64_t)blockIdx.x * stride;         // first output block of this workgroup
+    const uint64_t cb = first_block + (uint64_t)blockIdx.x * stride; // first output block of this workgroup (checkpoints[0] = block first_block)
     for (int i = threadIdx.x; i < kMtN; i += kBlock) mt[i] = checkpoints[(uint64_t)blockIdx.x * kMtN + i];
     __syncthreads();
     const uint64_t last = min(cb + stride, num_blocks);
@@ -618,25 +618,30 @@ __global__ __launch_bounds__(kBlock) void selftest_sqrt_kernel(int variant, uint
 }
 
 // ---- kernel: self-test of the shared-reciprocal divide --------------------------------------
-// Operand set i of [begin, begin+count): three numerators built from a counter hash, the divisor
-// formed from them exactly as the shading step does (sqrt of the sum of squares); a quarter of the
-// sets use special mantissas (all ones, 1.0, powers of two, one-bit neighbours), exponents at the
-// edges of the accepted range and signed zeros.  Every set the validity flags accept must give the
-// three quotients of the plain `/` bit for bit.
+// Operand set i of [begin, begin+count): three numerators built from a counter hash; a quarter of the sets use
+// special mantissas (all ones, 1.0, powers of two, one-bit neighbours), exponents at the edges of the accepted
+// range and signed zeros.  The divisor is formed in one of three ways, chosen by the counter:
+//   0  as the K-mode shading step does: sqrtf of the fp32 sum of squares (rt_helper.h:641-658)
+//   1  as the O-mode shading step does: sqrtf of the float64-accumulated sum of float32 squares (gen_data.py:347)
+//   2  INDEPENDENT of the numerators: any float in the accepted range [2^-48, 2^30] (len2 := its square, only the
+//      validity flags look at it), so the sequence is not only checked on |quotient| <= 1
+// Both forms of the sequence (div3_shared with its own flags, div3_packed under div3_operands_ok) must give the
+// three quotients of the plain `/` bit for bit on every set their validity test accepts.
 __global__ __launch_bounds__(kBlock) void selftest_div3_kernel(uint64_t begin, uint64_t count,
                                                                unsigned long long *result) {
 #if defined(__HIP_DEVICE_COMPILE__)
     const uint64_t stride = (uint64_t)gridDim.x * kBlock;
     unsigned long long bad = 0, first = ~0ull, accepted = 0;
     for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < count; i += stride) {
-        uint64_t h = splitmix64(begin + i);
+        const uint64_t ctr = begin + i;
+        uint64_t h = splitmix64(ctr);
         float v[3];
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             h = splitmix64(h);
             // exponents over the whole accepted range and a little beyond it on both sides
             uint32_t man = (uint32_t)h & 0x7fffffu, ex = 127u - 100u + (uint32_t)((h >> 23) % 134u), sg = (uint32_t)(h >> 63);
-            if (((begin + i) & 3u) == 0u) {
+            if ((ctr & 3u) == 0u) {
                 const uint32_t pick = (uint32_t)(h >> 40) & 7u;
                 man = pick == 0 ? 0x7fffffu : pick == 1 ? 0u : pick == 2 ? 1u : pick == 3 ? 0x7ffffeu
                     : pick == 4 ? 0x400000u : pick == 5 ? 0x3fffffu : pick == 6 ? 0x400001u : man;
@@ -644,20 +649,48 @@ __global__ __launch_bounds__(kBlock) void selftest_div3_kernel(uint64_t begin, u
             }
             v[k] = __uint_as_float((sg << 31) | (ex << 23) | man);
         }
-        if (((begin + i) & 63u) == 1u) v[((begin + i) >> 6) % 3u] = ((begin + i) & 64u) ? 0.0f : -0.0f; // zero numerators
-        // the divisor exactly as the shading step forms it (K-mode order; O-mode differs by one rounding)
-        float len2 = 0.0f + v[0] * v[0];
-        len2 = len2 + v[1] * v[1];
-        len2 = len2 + v[2] * v[2];
-        const float d = sqrtf(len2);
-        float ux, uy, uz, amin = 1.0f;
-        uint32_t hiflag = 0;
-        div3_shared(v[0], v[1], v[2], d, len2, ux, uy, uz, amin, hiflag);
-        if (amin < 0x1p-96f || (int32_t)hiflag < 0) continue; // the kernel redoes these with '/'
-        ++accepted;
+        if ((ctr & 63u) == 1u) v[(ctr >> 6) % 3u] = (ctr & 64u) ? 0.0f : -0.0f; // zero numerators
+        const uint32_t how = (uint32_t)((ctr >> 2) % 3u);
+        float len2, d;
+        if (how == 0) {
+            len2 = 0.0f + v[0] * v[0];
+            len2 = len2 + v[1] * v[1];
+            len2 = len2 + v[2] * v[2];
+            d = sqrtf(len2);
+        } else if (how == 1) {
+            const float p0 = v[0] * v[0], p1 = v[1] * v[1], p2 = v[2] * v[2];
+            double acc = 0.0 + (double)p0;
+            acc = acc + (double)p1;
+            acc = acc + (double)p2;
+            len2 = (float)acc;
+            d = sqrtf(len2);
+        } else {
+            h = splitmix64(h);
+            uint32_t man = (uint32_t)h & 0x7fffffu;
+            const uint32_t ex = 127u - 50u + (uint32_t)((h >> 23) % 84u);     // 2^-50 .. 2^33: a little beyond both ends
+            if ((ctr & 3u) == 0u) man = ((h >> 40) & 1u) ? 0x7fffffu : 0u;
+            d = __uint_as_float((ex << 23) | man);
+            len2 = d * d;
+        }
         const float wx = v[0] / d, wy = v[1] / d, wz = v[2] / d;
-        if (__float_as_uint(ux) != __float_as_uint(wx) || __float_as_uint(uy) != __float_as_uint(wy) ||
-            __float_as_uint(uz) != __float_as_uint(wz)) { ++bad; if (first == ~0ull) first = begin + i; }
+        {   // the scalar form with its own validity flags (grid traversal's shading step)
+            float ux, uy, uz, amin = 1.0f;
+            uint32_t hiflag = 0;
+            div3_shared(v[0], v[1], v[2], d, len2, ux, uy, uz, amin, hiflag);
+            if (!(amin < 0x1p-96f || (int32_t)hiflag < 0)) {
+                ++accepted;
+                if (__float_as_uint(ux) != __float_as_uint(wx) || __float_as_uint(uy) != __float_as_uint(wy) ||
+                    __float_as_uint(uz) != __float_as_uint(wz)) { ++bad; if (first == ~0ull) first = ctr; }
+            }
+        }
+        if (div3_operands_ok(len2, v[0], v[1], v[2])) {   // the packed form of the 8-sphere bounce block
+            ++accepted;
+            f2 uxy;
+            float uz;
+            div3_packed(f2{v[0], v[1]}, v[2], d, uxy, uz);
+            if (__float_as_uint(uxy.x) != __float_as_uint(wx) || __float_as_uint(uxy.y) != __float_as_uint(wy) ||
+                __float_as_uint(uz) != __float_as_uint(wz)) { ++bad; if (first == ~0ull) first = ctr; }
+        }
     }
     if (bad) { atomicAdd(&result[0], bad); atomicMin(&result[1], first); }
     atomicAdd(&result[2], accepted);

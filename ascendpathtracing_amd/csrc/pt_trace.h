@@ -299,21 +299,7 @@ __device__ __forceinline__ uint64_t bounce_ns8_v2(const Scene8 &sc, const Tab8 t
     }
     f2 uxy;
     float uz;
-    {   // div3_shared (pt_core.h) without its own min/flag bookkeeping, x and y packed
-        const float r0 = __builtin_amdgcn_rcpf(L);
-        const float e0 = __builtin_fmaf(-L, r0, 1.0f);
-        const float r = __builtin_fmaf(e0, r0, r0);
-        const f2 nL = {-L, -L}, rr = {r, r};
-        f2 q2 = nxy * r;
-        f2 e2 = __builtin_elementwise_fma(nL, q2, nxy);
-        q2 = __builtin_elementwise_fma(e2, rr, q2);
-        e2 = __builtin_elementwise_fma(nL, q2, nxy);
-        uxy = __builtin_elementwise_fma(e2, rr, q2);
-        float q = nz * r, e = __builtin_fmaf(-L, q, nz);
-        q = __builtin_fmaf(e, r, q);
-        e = __builtin_fmaf(-L, q, nz);
-        uz = __builtin_fmaf(e, r, q);
-    }
+    div3_packed(nxy, nz, L, uxy, uz);           // pt_core.h; validity = the amin / huge tests of this function
     const f2 pr = dxy * uxy;
     const float pz = s.dz * uz;
     float dot;

@@ -102,11 +102,11 @@ int do_render_paths(const apt_context::Values &cv, const apt_render_params *p, v
     int rc = check_params(p);
     if (rc) return rc;
     if (!rays || !spheres || !colors) return fail(APT_ERR_ARG, "rays/spheres/colors must be non-null%s");
-    const uint64_t n = (uint64_t)p->width * p->height * 4u * p->samples;
+    const uint64_t n_image = (uint64_t)p->width * p->height * 4u * p->samples;
     const uint64_t b = p->path_begin;
-    if (b > n) return fail(APT_ERR_ARG, "path_begin beyond the image%s");
-    const uint64_t c = p->path_count ? p->path_count : n - b;
-    if (b + c > n) return fail(APT_ERR_ARG, "path range beyond the image%s");
+    if (b > n_image) return fail(APT_ERR_ARG, "path_begin beyond the image%s");
+    const uint64_t c = p->path_count ? p->path_count : n_image - b;
+    if (b + c > n_image) return fail(APT_ERR_ARG, "path range beyond the image%s");
     if (c == 0) return APT_OK;
     const uint64_t blocks = (c + kBlock - 1) / kBlock;
     if (blocks > 0x7fffffffull) return fail(APT_ERR_ARG, "path_count too large for one launch; shard it%s");
@@ -116,6 +116,12 @@ int do_render_paths(const apt_context::Values &cv, const apt_render_params *p, v
     const bool retire = p->flags & APT_FLAG_RETIRE;
     const dim3 grid((unsigned)blocks);
     const int sck = ns8 ? kScene8 : (ta.grid ? kSceneGrid : kSceneTiles);
+    uint64_t n = n_image;
+    if (p->flags & APT_FLAG_BAND_BUFFERS) { // planes of c floats holding paths [b, b+c): same indexing through a shifted base
+        n = c;
+        rays -= b;
+        colors -= b;
+    }
     if (retire && ns8) { // wave-level queue: one wave per kQueueChunk consecutive paths
         const uint64_t waves = (c + kQueueChunk - 1) / kQueueChunk;
         const dim3 qgrid((unsigned)((waves + kBlock / 64 - 1) / (kBlock / 64)));
@@ -471,14 +477,15 @@ int apt_gen_rays_device(const apt_render_params *p, void *stream, float *rays) {
     if (blocks > 0x7fffffffull) return fail(APT_ERR_ARG, "path_count too large for one launch; shard it%s");
     Camera cam;
     camera_init(cam, p->width, p->height);
+    const bool band = p->flags & APT_FLAG_BAND_BUFFERS;
     hipLaunchKernelGGL(gen_rays_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, cam, p->width,
-                       p->height, p->samples, p->seed, n, b, c, rays);
+                       p->height, p->samples, p->seed, band ? c : n, b, c, band ? rays - b : rays);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? APT_OK : hip_fail(e);
 }
 
-int apt_gen_rays_mt_device(const apt_render_params *p, void *stream, const uint32_t *checkpoints, uint32_t stride,
-                           uint64_t num_checkpoints, float *rays) {
+int apt_gen_rays_mt_device_ex(const apt_render_params *p, void *stream, const uint32_t *checkpoints, uint32_t stride,
+                              uint64_t num_checkpoints, uint64_t first_block, float *rays) {
     clear_error();
     int rc = check_params(p);
     if (rc) return rc;
@@ -489,30 +496,42 @@ int apt_gen_rays_mt_device(const apt_render_params *p, void *stream, const uint3
     const uint64_t c = p->path_count ? p->path_count : n - b;
     if (b + c > n) return fail(APT_ERR_ARG, "path range beyond the image%s");
     if (c == 0) return APT_OK;
-    const uint64_t num_blocks = (n + kPathsPerBlock - 1) / kPathsPerBlock;
-    const uint64_t need = (num_blocks + stride - 1) / stride;
-    if (num_checkpoints < need) return fail(APT_ERR_ARG, "not enough MT19937 checkpoints for this image%s");
-    if (need > 0x7fffffffull) return fail(APT_ERR_ARG, "too many checkpoints for one launch%s");
+    const uint64_t num_blocks = (n + kPathsPerBlock - 1) / kPathsPerBlock;           // of the whole stream
+    const uint64_t blk_lo = b / kPathsPerBlock, blk_hi = (b + c + kPathsPerBlock - 1) / kPathsPerBlock; // blocks the range touches
+    if (blk_lo < first_block) return fail(APT_ERR_ARG, "path range starts before the checkpoint window%s");
+    const uint64_t cp_lo = (blk_lo - first_block) / stride, cp_hi = (blk_hi - first_block + stride - 1) / stride;
+    if (cp_hi > num_checkpoints) return fail(APT_ERR_ARG, "not enough MT19937 checkpoints for this path range%s");
+    if (cp_hi - cp_lo > 0x7fffffffull) return fail(APT_ERR_ARG, "too many checkpoints for one launch%s");
     Camera cam;
     camera_init(cam, p->width, p->height);
-    hipLaunchKernelGGL(gen_rays_mt_kernel, dim3((unsigned)need), dim3(kBlock), 0, (hipStream_t)stream, checkpoints,
-                       stride, num_blocks, cam, p->width, p->height, p->samples, n, b, b + c, rays);
+    const bool band = p->flags & APT_FLAG_BAND_BUFFERS;
+    // one workgroup per checkpoint the range touches (workgroups of untouched checkpoints would only skip)
+    hipLaunchKernelGGL(gen_rays_mt_kernel, dim3((unsigned)(cp_hi - cp_lo)), dim3(kBlock), 0, (hipStream_t)stream,
+                       checkpoints + cp_lo * kMtN, stride, first_block + cp_lo * stride, num_blocks, cam, p->width, p->height,
+                       p->samples, band ? c : n, b, b + c, band ? rays - b : rays);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? APT_OK : hip_fail(e);
 }
 
-int apt_decode_color_device(const apt_render_params *p, void *stream, const float *colors, float *fb, uint8_t *fb_u8) {
+int apt_gen_rays_mt_device(const apt_render_params *p, void *stream, const uint32_t *checkpoints, uint32_t stride,
+                           uint64_t num_checkpoints, float *rays) {
+    return apt_gen_rays_mt_device_ex(p, stream, checkpoints, stride, num_checkpoints, 0, rays);
+}
+
+int apt_decode_color_band(const apt_render_params *p, void *stream, const float *colors, uint64_t pixel_count, float *fb,
+                          uint8_t *fb_u8) {
     clear_error();
     int rc = check_params(p);
     if (rc) return rc;
     if (!colors || !fb) return fail(APT_ERR_ARG, "colors/fb must be non-null%s");
+    if (pixel_count == 0) return APT_OK;
     LeafProg lp;
     if ((rc = make_leaf_prog(p->samples, lp))) return rc;
-    const uint64_t npix = (uint64_t)p->width * p->height;
+    const uint64_t npix = pixel_count;                    // the band is decoded like an image of pixel_count pixels
     const bool wide = p->samples >= 8;                    // 8 lanes per sub-pixel row: coalesced loads
     const uint64_t lanes = npix * 3 * 4 * (wide ? 8 : 1);
     const uint64_t blocks = (lanes + kBlock - 1) / kBlock;
-    if (blocks > 0x7fffffffull) return fail(APT_ERR_ARG, "image too large for one launch%s");
+    if (blocks > 0x7fffffffull) return fail(APT_ERR_ARG, "band too large for one launch%s");
     if (wide)
         hipLaunchKernelGGL(decode_color_kernel8, dim3((unsigned)std::min<uint64_t>(blocks, 256u * 64u)), dim3(kBlock), 0, (hipStream_t)stream, colors,
                            p->samples, npix, lp, fb, fb_u8);
@@ -521,6 +540,12 @@ int apt_decode_color_device(const apt_render_params *p, void *stream, const floa
                            p->samples, npix, lp, fb, fb_u8);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? APT_OK : hip_fail(e);
+}
+
+int apt_decode_color_device(const apt_render_params *p, void *stream, const float *colors, float *fb, uint8_t *fb_u8) {
+    clear_error();
+    if (!p) return fail(APT_ERR_ARG, "params is null%s");
+    return apt_decode_color_band(p, stream, colors, (uint64_t)p->width * p->height, fb, fb_u8);
 }
 
 } // extern "C"

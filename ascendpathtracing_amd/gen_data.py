@@ -40,6 +40,22 @@ def mt19937_checkpoints(num_paths, seed=0, stride=64):
     return states
 
 
+def mt19937_checkpoints_window(first_block, num_blocks, seed=0, stride=64, state_in=None):
+    """Checkpoints of output blocks first_block + k*stride (k < ceil(num_blocks/stride)) -> (uint32 [n][624], raw state
+    of block first_block + num_blocks).  state_in = raw state of block first_block (chains windows, or a stored state);
+    None walks there from the seed (first_block + 1 sequential twists)."""
+    n = (num_blocks + stride - 1) // stride
+    states = np.empty((n, 624), dtype=np.uint32)
+    out = np.empty(624, dtype=np.uint32)
+    st = None if state_in is None else np.ascontiguousarray(state_in, dtype=np.uint32)
+    u32p = ctypes.POINTER(ctypes.c_uint32)
+    check(lib().apt_mt19937_checkpoints_window(None if st is None else st.ctypes.data_as(u32p), ctypes.c_uint32(seed),
+                                               ctypes.c_uint64(first_block), ctypes.c_uint64(num_blocks), ctypes.c_uint32(stride),
+                                               states.ctypes.data_as(u32p), out.ctypes.data_as(u32p)),
+          "apt_mt19937_checkpoints_window")
+    return states, out
+
+
 def gen_rays_device(w, h, s, seed=0, stride=64, checkpoints=None, stream=None):
     """gen_rays on the GPU, bit-exact with the reference (np.random.seed(seed) MT19937 stream):
     -> torch float32 [6][N] on the device.  `checkpoints` (a CUDA int32/uint32 tensor from

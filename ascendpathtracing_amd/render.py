@@ -276,18 +276,75 @@ def test_scene(params: RenderParams, rays, spheres, stream=None):
     return out.view(3, -1)
 
 
-def render_reference_frame(w, h, s, depth=5, seed=0, spheres=None, mode=None, flags=0, stream=None):
+def render_reference_frame(w, h, s, depth=5, seed=0, spheres=None, mode=None, flags=0, stream=None, band_pixels=None,
+                           pixel_begin=0, pixel_count=None, mt_state=None):
     """The reference's whole pipeline on the device, bit-exact with running scripts/gen_data.py
     (np.random.seed(seed); gen_rays; gen_spheres; test_soa) and scripts/data_visualization.py:
     MT19937 gen_rays -> render (O-mode by default = the NumPy oracle's arithmetic) -> decode_color.
-    -> (fb float32 [3][W*H], fb_u8 uint8 [W*H][3], colors [3][N]); not synchronised."""
+
+    band_pixels=None: three whole-frame launches with [6][N] / [3][N] intermediates (36 bytes per path: 19 GB at C2)
+        -> (fb float32 [3][W*H], fb_u8 uint8 [W*H][3], colors [3][N]); not synchronised.
+    band_pixels=B: the same pipeline band by band in band-relative buffers (APT_FLAG_BAND_BUFFERS) of B pixels
+        (36*4*S*B bytes, e.g. 604 MB for B = 65536 at S = 64), for pixels [pixel_begin, pixel_begin+pixel_count)
+        -> (fb [3][pixel_count], fb_u8 [pixel_count][3], None).  The MT19937 checkpoints are made window by
+        window on the host (chained); mt_state = (block, raw uint32[624] state of that block) lets a far window start
+        without walking the stream from the seed (C3's last band is 1.1e8 blocks in)."""
+    import numpy as np
     from . import gen_data
-    from ._lib import APT_MODE_ORACLE, make_params
+    from ._lib import APT_FLAG_BAND_BUFFERS, APT_MODE_ORACLE, make_params
     require_gpu()
     if spheres is None:
         spheres = torch.from_numpy(gen_data.gen_spheres()).cuda()
-    p = make_params(w, h, s, depth=depth, mode=APT_MODE_ORACLE if mode is None else mode, flags=flags)
-    rays = gen_data.gen_rays_device(w, h, s, seed=seed, stream=stream)
-    colors = render_paths(p, rays.reshape(-1), spheres, stream=stream)
-    fb, u8 = decode_color_device(p, colors, stream=stream)
-    return fb, u8, colors
+    mode = APT_MODE_ORACLE if mode is None else mode
+    if band_pixels is None:
+        p = make_params(w, h, s, depth=depth, mode=mode, flags=flags)
+        rays = gen_data.gen_rays_device(w, h, s, seed=seed, stream=stream)
+        colors = render_paths(p, rays.reshape(-1), spheres, stream=stream)
+        fb, u8 = decode_color_device(p, colors, stream=stream)
+        return fb, u8, colors
+    npix = w * h
+    if pixel_count is None:
+        pixel_count = npix - pixel_begin
+    per_pixel, stride = 4 * s, 64
+    fb = torch.empty((3, pixel_count), dtype=torch.float32, device="cuda")
+    u8 = torch.empty((pixel_count, 3), dtype=torch.uint8, device="cuda")
+    rays = torch.empty(6 * band_pixels * per_pixel, dtype=torch.float32, device="cuda")
+    colors = torch.empty(3 * band_pixels * per_pixel, dtype=torch.float32, device="cuda")
+    st = _stream_handle(stream)
+    state_blk, state = (None, None) if mt_state is None else mt_state
+
+    def advance(raw, blk_from, blk_to):     # raw state of block blk_from -> raw state of block blk_to (host, sequential)
+        if blk_to == blk_from:
+            return np.array(raw, dtype=np.uint32)
+        return gen_data.mt19937_checkpoints_window(blk_from, blk_to - blk_from, seed, 1 << 30, raw)[1]
+
+    for q0 in range(pixel_begin, pixel_begin + pixel_count, band_pixels):
+        nq = min(band_pixels, pixel_begin + pixel_count - q0)
+        b, c = q0 * per_pixel, nq * per_pixel
+        blk0, blk1 = b // 156, (b + c + 155) // 156
+        if state_blk is not None and state_blk > blk0:
+            raise _lib.AptError("mt_state lies after the first path requested")
+        if state_blk is not None and state_blk < blk0:      # walk the stored state forward to this band (host, sequential)
+            state, state_blk = advance(state, state_blk, blk0), blk0
+        ck, nxt = gen_data.mt19937_checkpoints_window(blk0, blk1 - blk0, seed, stride, state if state_blk == blk0 else None)
+        # the window's end state is the raw state of block blk1; the next band starts at block (b + c) // 156 = blk1 or blk1 - 1
+        # (a band boundary inside a block), so keep the state of the LAST block of this window instead when they overlap
+        ck_d = torch.from_numpy(ck.view(np.int32)).cuda()
+        p = make_params(w, h, s, depth=depth, mode=mode, flags=flags | APT_FLAG_BAND_BUFFERS, path_begin=b, path_count=c)
+        check(lib().apt_gen_rays_mt_device_ex(ctypes.byref(p), st, ctypes.c_void_p(ck_d.data_ptr()), ctypes.c_uint32(stride),
+                                              ctypes.c_uint64(ck.shape[0]), ctypes.c_uint64(blk0), ctypes.c_void_p(rays.data_ptr())),
+              "apt_gen_rays_mt_device_ex")
+        check(lib().render_do_ex(ctypes.byref(p), st, ctypes.c_void_p(rays.data_ptr()), _dev_f32(spheres, "spheres"),
+                                 ctypes.c_void_p(colors.data_ptr())), "render_do_ex")
+        o = q0 - pixel_begin
+        fb_band = torch.empty((3, nq), dtype=torch.float32, device="cuda")
+        check(lib().apt_decode_color_band(ctypes.byref(p), st, ctypes.c_void_p(colors.data_ptr()), ctypes.c_uint64(nq),
+                                          ctypes.c_void_p(fb_band.data_ptr()), ctypes.c_void_p(u8[o:o + nq].data_ptr())),
+              "apt_decode_color_band")
+        fb[:, o:o + nq] = fb_band
+        torch.cuda.current_stream().synchronize()           # the checkpoint table of this band may now be freed / rays reused
+        state_blk, state = blk1, nxt
+        if (b + c) % 156:                                    # the next band starts inside block blk1 - 1: re-derive from this window's table
+            last_cp = (blk1 - 1 - blk0) // stride
+            state, state_blk = advance(ck[last_cp], blk0 + last_cp * stride, blk1 - 1), blk1 - 1
+    return fb, u8, None

@@ -65,6 +65,11 @@ enum {
     APT_FLAG_RETIRE = 1u,  /* result-preserving retirement of finished paths: a path     */
                            /* whose alive bit is cleared or whose throughput is (0,0,0)   */
                            /* stops bouncing; colours are bit-identical either way.       */
+    APT_FLAG_BAND_BUFFERS = 8u, /* render_do_ex / apt_gen_rays_device / apt_gen_rays_mt_device_ex: `rays` and  */
+                           /* `colors` hold ONLY paths [path_begin, path_begin+path_count): planes of      */
+                           /* path_count floats, element (plane k, path p) at [k*path_count + p-path_begin] */
+                           /* (default: full [6][N] / [3][N] buffers indexed by the absolute path).  With    */
+                           /* it the reference's exact pipeline runs band by band in a bounded buffer.       */
     APT_FLAG_EMISSION = 4u,/* colour = throughput * emission(light sphere) per channel       */
                            /* (spheres.bin planes 4..6) instead of the literal gain 12 of      */
                            /* render.cpp:194-196; identical on the reference scene (em = 12).  */
@@ -216,11 +221,29 @@ int apt_gen_rays_device(const apt_render_params *p, void *stream, float *rays);
 int apt_mt19937_checkpoints_host(uint32_t seed, uint64_t num_blocks, uint32_t stride, uint32_t *states);
 int apt_gen_rays_mt_device(const apt_render_params *p, void *stream, const uint32_t *checkpoints,
                            uint32_t stride, uint64_t num_checkpoints, float *rays);
+/* Windowed forms, for frames whose whole stream is too long to tabulate at once (C3: 1.7e10 paths):
+ *   apt_mt19937_checkpoints_window(state_in, seed, first_block, num_blocks, stride, states, state_out):
+ *       checkpoints of output blocks first_block + k*stride, k < ceil(num_blocks/stride).  state_in = the raw
+ *       624-word state of block first_block (from an earlier call's state_out, or a stored one), or NULL to twist
+ *       there from the seed (first_block+1 sequential twists).  state_out (or NULL) receives the raw state of
+ *       block first_block + num_blocks, so that windows chain.
+ *   apt_gen_rays_mt_device_ex: as apt_gen_rays_mt_device with a table whose entry 0 is block first_block;
+ *       the call's path range must lie inside the window; honours APT_FLAG_BAND_BUFFERS. */
+int apt_mt19937_checkpoints_window(const uint32_t *state_in, uint32_t seed, uint64_t first_block, uint64_t num_blocks,
+                                   uint32_t stride, uint32_t *states, uint32_t *state_out);
+int apt_gen_rays_mt_device_ex(const apt_render_params *p, void *stream, const uint32_t *checkpoints, uint32_t stride,
+                              uint64_t num_checkpoints, uint64_t first_block, float *rays);
 
 /* Device decode_color: colors [3][N] -> fb float32 [3][W*H] (+ fb_u8 [W*H][3] or NULL),
  * same arithmetic as scripts/data_visualization.py:20-59. */
 int apt_decode_color_device(const apt_render_params *p, void *stream, const float *colors,
                             float *fb, uint8_t *fb_u8);
+
+/* The same for a band: colors_band = float32 [3][pixel_count*4*S] holding the paths of pixel_count consecutive
+ * pixels (APT_FLAG_BAND_BUFFERS layout) -> fb [3][pixel_count] (+ fb_u8 [pixel_count][3] or NULL).  decode_color
+ * does not depend on where in the image the pixels lie. */
+int apt_decode_color_band(const apt_render_params *p, void *stream, const float *colors_band, uint64_t pixel_count,
+                          float *fb, uint8_t *fb_u8);
 
 /* ---- host-side helpers (no GPU) -------------------------------------------------------
  * Host gen_rays, bit-exact with scripts/gen_data.py:21-75 under np.random.seed(seed)

@@ -97,6 +97,20 @@ def gen_rays(w, h, s, seed=0):
     return rays.reshape(6, n)
 
 
+def gen_rays_window(w, h, s, first_block, first_path, count, seed=0, state_in=None):
+    """MT19937 gen_rays for paths [first_path, first_path+count) -> (rays [6][count] band-relative, raw state of block
+    first_block uint32[624]).  state_in: that raw state (skips the walk from the seed)."""
+    rays = np.zeros(6 * count, dtype=np.float32)
+    st_out = np.zeros(624, dtype=np.uint32)
+    st_in = None if state_in is None else np.ascontiguousarray(state_in, dtype=np.uint32)
+    rc = lib().oracle_gen_rays_window(ctypes.c_uint32(w), ctypes.c_uint32(h), ctypes.c_uint32(s), ctypes.c_uint32(seed),
+                                      None if st_in is None else _ptr(st_in, ctypes.c_uint32), ctypes.c_uint64(first_block),
+                                      ctypes.c_uint64(first_path), ctypes.c_uint64(count), _ptr(rays), _ptr(st_out, ctypes.c_uint32))
+    if rc:
+        raise ValueError("oracle_gen_rays_window: first_path lies before the window")
+    return rays.reshape(6, count), st_out
+
+
 def gen_rays_counter(params):
     n = params.width * params.height * 4 * params.samples
     rays = np.zeros(6 * n, dtype=np.float32)

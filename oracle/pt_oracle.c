@@ -329,6 +329,37 @@ int oracle_gen_rays(uint32_t w, uint32_t h, uint32_t s, uint32_t seed, float *ra
     return 0;
 }
 
+/* gen_rays for a WINDOW of the np.random stream (frames whose whole stream is too long to walk: C3 has 1.7e10 paths):
+ * state_in = the raw 624-word generator state whose tempering is output block first_block (624 words = the 4 words
+ * of paths [156*first_block, 156*first_block+156)), or NULL to walk there from the seed.  Writes band-relative planes
+ * rays[k*count + (p - first_path)] for paths [first_path, first_path+count), first_path >= 156*first_block.
+ * state_out (or NULL): the raw state of block first_block (what a later call can pass as state_in). */
+int oracle_gen_rays_window(uint32_t w, uint32_t h, uint32_t s, uint32_t seed, const uint32_t *state_in, uint64_t first_block,
+                           uint64_t first_path, uint64_t count, float *rays, uint32_t *state_out) {
+    mt19937 m;
+    if (state_in) { memcpy(m.mt, state_in, sizeof m.mt); m.idx = 0; }
+    else {
+        mt_seed(&m, seed);
+        for (uint64_t b = 0; b <= first_block; ++b) { m.idx = 624; (void)mt_next(&m); } /* one twist per block */
+        m.idx = 0;
+    }
+    if (state_out) memcpy(state_out, m.mt, sizeof m.mt);
+    if (first_path < first_block * 156u) return 1;
+    camera c; camera_init(&c, w, h);
+    for (uint64_t skip = first_block * 156u; skip < first_path; ++skip) { (void)mt_double(&m); (void)mt_double(&m); }
+    for (uint64_t q = 0; q < count; ++q) {
+        const uint64_t p = first_path + q;
+        uint64_t r = p / s;
+        uint32_t sx = r & 1, sy = (r >> 1) & 1; r >>= 2;
+        uint32_t j = (uint32_t)(r % h), i = (uint32_t)(r / h);
+        double u1 = mt_double(&m), u2 = mt_double(&m);
+        float ray[6];
+        camera_ray(&c, w, h, i, j, sy, sx, u1, u2, ray);
+        for (int k = 0; k < 6; ++k) rays[(uint64_t)k * count + q] = ray[k];
+    }
+    return 0;
+}
+
 /* the device-mode ray generator restated on the CPU: same camera maths, counter RNG */
 int oracle_gen_rays_counter(const oracle_params *P, float *rays) {
     camera c; camera_init(&c, P->width, P->height);

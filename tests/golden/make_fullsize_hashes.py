@@ -78,6 +78,40 @@ CASES = {
 }
 
 
+# The reference's EXACT pipeline (MT19937 gen_rays -> test_soa arithmetic (O-mode) -> decode_color) on pixel ranges of
+# the big configurations: "mt_state" names the committed generator state the window starts from (None = from the seed).
+MT_CASES = {
+    "C2_mt_first_band": dict(w=1920, h=1080, s=64, depth=8, ranges=[[0, 8192]], mt_state=None),
+    "C3_mt_last_column": dict(w=4096, h=4096, s=256, depth=8, ranges=[[4096 * 4096 - 4096, 4096]], mt_state="mt19937_state_c3.npz"),
+}
+
+
+def run_mt_case(name, case, threads):
+    w, h, s = case["w"], case["h"], case["s"]
+    sph = oracle.gen_spheres()
+    t0 = time.time()
+    fb_sha, u8_sha = [], []
+    for b, c in case["ranges"]:
+        first_path, count = b * 4 * s, c * 4 * s
+        state, blk = None, first_path // 156
+        if case["mt_state"]:
+            f = np.load(os.path.join(ROOT, "tests", "golden", case["mt_state"]))
+            assert int(f["block"]) == blk, (int(f["block"]), blk)
+            state = f["state"]
+        rays, _ = oracle.gen_rays_window(w, h, s, blk, first_path, count, seed=0, state_in=state)
+        # the band as an image of c x 1 pixels: the render does not look at pixel coordinates, decode_color only at the grouping
+        p = oracle.make_params(c, 1, s, depth=case["depth"], mode=oracle.MODE_O, flags=oracle.FLAG_RETIRE)
+        colors, _ = oracle.render_paths(p, rays, sph, threads=threads)
+        _, fb, u8 = oracle.decode_color(colors, c, 1, s)
+        fb_sha.append(sha(fb))
+        u8_sha.append(sha(u8))
+    entry = dict(case)
+    entry.update({"fb_sha256": fb_sha, "u8_sha256": u8_sha, "oracle_seconds": round(time.time() - t0, 1),
+                  "pipeline": "oracle_gen_rays_window (MT19937, np.random.seed(0)) -> oracle_render_paths O-mode -> oracle_decode_color"})
+    print(f"{name}: {sum(c for _, c in case['ranges'])} pixels, {entry['oracle_seconds']} s", flush=True)
+    return entry
+
+
 def scene_of(case):
     sc = case["scene"]
     if sc == "demo":
@@ -130,6 +164,8 @@ def main():
     names = [n for n in CASES if not args.only or n in args.only.split(",")]
     for n in names:
         out.setdefault("cases", {})[n] = run_case(n, CASES[n], args.threads)
+    for n in [n for n in MT_CASES if not args.only or n in args.only.split(",")]:
+        out.setdefault("mt_cases", {})[n] = run_mt_case(n, MT_CASES[n], args.threads)
     out["generator"] = "tests/golden/make_fullsize_hashes.py (oracle/pt_oracle.c, gcc -O2 -ffp-contract=off)"
     out["layout"] = "per range: sha256(float32 fb[3][count]) and sha256(uint8 u8[count][3]); ranges are [pixel_begin, pixel_count]"
     with open(OUT, "w") as f:

@@ -161,3 +161,52 @@ def test_committed_hashes_are_the_oracles(oracle):
             fb, u8, _, _ = oracle.render_frame(p, oracle.gen_spheres(), pixel_begin=b, pixel_count=c,
                                                threads=min(8, oracle.max_threads()))
             assert sha(fb) == case["fb_sha256"][k] and sha(u8) == case["u8_sha256"][k], (name, k)
+
+
+def _mt_cases():
+    with open(os.path.join(ROOT, "tests", "golden", "fullsize_hashes.json")) as f:
+        return json.load(f).get("mt_cases", {})
+
+
+@pytest.mark.gpu
+def test_exact_reference_pipeline_in_bands_c2_and_c3(apt):
+    """(f)1: the reference's exact pipeline (MT19937 gen_rays -> O-mode render -> decode_color) band by band in a bounded
+    buffer, against the oracle's hashes: the first 8192 pixels of C2, and the LAST image column of C3 (path indices
+    around 1.7e10, generator state taken from the committed fixture instead of walking 1.1e8 blocks)."""
+    import torch
+    cases = _mt_cases()
+    assert set(cases) >= {"C2_mt_first_band", "C3_mt_last_column"}
+    for name, case in cases.items():
+        state = None
+        if case["mt_state"]:
+            f = np.load(os.path.join(ROOT, "tests", "golden", case["mt_state"]))
+            state = (int(f["block"]), f["state"])
+        for k, (b, c) in enumerate(case["ranges"]):
+            torch.cuda.reset_peak_memory_stats()
+            base = torch.cuda.memory_allocated()
+            fb, u8, _ = apt.render.render_reference_frame(case["w"], case["h"], case["s"], depth=case["depth"], seed=0,
+                                                          band_pixels=1024, pixel_begin=b, pixel_count=c, mt_state=state)
+            torch.cuda.synchronize()
+            assert torch.cuda.max_memory_allocated() - base < (1 << 30)            # bounded intermediates
+            assert sha(fb.cpu().numpy()) == case["fb_sha256"][k] and sha(u8.cpu().numpy()) == case["u8_sha256"][k], (name, k)
+
+
+@pytest.mark.gpu
+def test_exact_reference_pipeline_whole_c2_banded_equals_unbanded(apt):
+    """render_reference_frame at C2 in bands of 65536 pixels (0.6 GB of intermediates instead of
+    19 GB) is bit-equal to the three whole-frame launches."""
+    import torch
+    w, h, s = 1920, 1080, 64
+    torch.cuda.reset_peak_memory_stats()
+    base = torch.cuda.memory_allocated()
+    fb_b, u8_b, _ = apt.render.render_reference_frame(w, h, s, depth=8, seed=0, band_pixels=65536)
+    torch.cuda.synchronize()
+    peak = torch.cuda.max_memory_allocated() - base
+    assert peak < (1 << 30), peak
+    fb, u8, colors = apt.render.render_reference_frame(w, h, s, depth=8, seed=0)
+    torch.cuda.synchronize()
+    del colors
+    assert torch.equal(fb.view(torch.int32), fb_b.view(torch.int32)) and torch.equal(u8, u8_b)
+    case = _mt_cases()["C2_mt_first_band"]
+    b, c = case["ranges"][0]
+    assert sha(fb[:, b:b + c].cpu().numpy()) == case["fb_sha256"][0] and sha(u8[b:b + c].cpu().numpy()) == case["u8_sha256"][0]
