@@ -175,7 +175,10 @@ __global__ __launch_bounds__(kBlock, (RETIRE && SC == kScene8 && GROUP == 8) ? 4
         } else {          // 8 <= n <= 128: r[j] chains, tree, tail
             const uint32_t nfull = n & ~7u;
             if (RETIRE && NS8) {
-                // Active-ray compaction with a wave-level work queue.  The 8 sub-pixel groups of the
+                // Active-ray compaction with a wave-level work queue.  (The same queue around grid_segment() for large
+                // scenes is bit-identical but slower than the plain per-lane walk with wave-level early exit -- C4 256 spp:
+                // 288 / 318 / 371 ms at 6 / 5 / 4 waves per SIMD against 232 ms: the walk is latency bound and the queue's
+                // extra state costs occupancy; measured in round 2, not kept.)  The 8 sub-pixel groups of the
                 // wave have 8*nfull samples in this leaf; instead of binding sample k of group g to
                 // lane (g, k mod 8), any lane that runs out of work takes the next unissued sample:
                 // a ballot of the lanes with an empty one-ray slot, a prefix count (mbcnt) as the

@@ -523,184 +523,208 @@ __device__ __forceinline__ uint32_t trace_dyn(const float *__restrict__ sph, flo
 // and the arg-min is order independent (equal t -> lower sphere index, the brute-force loop's rule).
 // The geometric argument needs a unit-length direction (the reference's roots are only the geometric
 // ray parameters then): lanes whose |d|^2 is not within 1e-3 of 1, or not finite, test every sphere.
-template <int MODE, bool RETIRE>
-__device__ __forceinline__ uint32_t trace_grid(const float *__restrict__ sph, const uint32_t *__restrict__ grid,
-                                               PathState &s, bool valid, const TraceArgs &ta, uint64_t path) {
-    const GridHeader &h = *reinterpret_cast<const GridHeader *>(grid);
+__device__ __forceinline__ void grid_stats(const TraceArgs &ta, uint32_t n_cells, uint32_t n_tests) {
+    if (ta.traced) { // statistics: cells visited / candidates tested (per lane, summed over the wave)
+        unsigned long long c = n_cells, t = n_tests;
+        for (int off = 32; off > 0; off >>= 1) { c += __shfl_xor(c, off, 64); t += __shfl_xor(t, off, 64); }
+        if ((threadIdx.x & 63) == 0) { atomicAdd(ta.traced + 1, c); atomicAdd(ta.traced + 2, t); }
+    }
+}
+
+struct GridCtx { // what one segment through the grid needs besides the path (wave-uniform)
+    const GridHeader *h;
+    const float *sph;
+    const uint32_t *grid;
+    const TraceArgs *ta;
+};
+
+// One segment (intersect through the grid, shade) for the lanes with !fin; others only take part in the wave-uniform
+// parts.  Russian roulette and the counters are the caller's.
+template <int MODE>
+__device__ __forceinline__ void grid_segment(const GridCtx &ctx, PathState &s, bool fin, uint32_t &n_cells, uint32_t &n_tests) {
+    const GridHeader &h = *ctx.h;
+    const TraceArgs &ta = *ctx.ta;
+    const float *__restrict__ sph = ctx.sph;
+    const uint32_t *__restrict__ grid = ctx.grid;
     const uint32_t ns = ta.ns;
     const uint32_t *large = grid + h.off_large, *cells = grid + h.off_cells, *items = grid + h.off_items;
     const float4 *geom = reinterpret_cast<const float4 *>(grid + h.off_geom);
     const float4 *item_geom = reinterpret_cast<const float4 *>(grid + h.off_item_geom);
     const float *colx = sph + 7 * (size_t)ns, *coly = sph + 8 * (size_t)ns, *colz = sph + 9 * (size_t)ns;
-    const uint64_t rr_key = ta.rr_start ? rr_path_key(ta.seed, path) : 0;
     const int n0 = (int)h.n[0], n1 = (int)h.n[1], n2 = (int)h.n[2];
     // A grid built for another scene (or a stale / foreign pointer that still carries the magic) would index past
     // the sphere table: such a buffer is not walked at all -- every sphere is tested straight from the [10][Ns]
     // planes instead (same image, brute-force speed).  Wave-uniform.
     const bool grid_ok = h.magic == kGridMagic && h.num_spheres == ns;
     const float *r2p = sph, *cxp = sph + ns, *cyp = sph + 2 * (size_t)ns, *czp = sph + 3 * (size_t)ns;
+        float tmin = kMissT;
+    int idx = (MODE == kModeOracle) ? -1 : 0;
+    auto test_geom = [&](const float4 g, uint32_t k) {
+        const HitPre hp = intersect_pre(g.x, g.y, g.z, g.w, s.oxy.x, s.oxy.y, s.oz, s.dxy.x, s.dxy.y, s.dz);
+        if (hp.disc >= 0.0f) {
+            const float t = intersect_post(hp, ta.eps);
+            if (t < tmin || (t == tmin && (int)k < idx)) { tmin = t; idx = (int)k; }
+        }
+    };
+    auto test = [&](uint32_t k) { ++n_tests; test_geom(geom[k], k); };
+    // A candidate of the walk is identified by its position in the item list; the sphere index (one more
+    // dependent load per candidate) is only fetched when it matters: on an exact tie of t -- mostly the same
+    // sphere met again in the next cell -- and once at the end for the winner.
+    uint32_t pos = ~0u; // item position of the running minimum, ~0u while `idx` itself is authoritative
+    auto test_item = [&](const float4 g, uint32_t i) {
+        const HitPre hp = intersect_pre(g.x, g.y, g.z, g.w, s.oxy.x, s.oxy.y, s.oz, s.dxy.x, s.dxy.y, s.dz);
+        if (hp.disc >= 0.0f) {
+            const float t = intersect_post(hp, ta.eps);
+            if (t < tmin) { tmin = t; pos = i; }
+            else if (t == tmin) {
+                const int cur = (pos != ~0u) ? (int)items[pos] : idx;
+                if ((int)items[i] < cur) pos = i;
+            }
+        }
+    };
+    // The large spheres are tested by every lane of the wave and (walls) hit by every ray, so the `disc >= 0`
+    // skip never fires for them: the exact single-rsq sqrt (pt_core.h) instead of sqrtf()'s full expansion.  A
+    // negative discriminant gives NaN roots and select_root's kMissT like the skipped form; +inf gives NaN
+    // instead of +inf, and neither can beat tmin <= kMissT.
+    auto test_large = [&](const float4 g, uint32_t k) {
+        ++n_tests;
+        const HitPre hp = intersect_pre(g.x, g.y, g.z, g.w, s.oxy.x, s.oxy.y, s.oz, s.dxy.x, s.dxy.y, s.dz);
+        float q;
+#if defined(__HIP_DEVICE_COMPILE__) // the sqrt variants are device-only builtins
+        float am = 1.0f;
+        q = sqrt_rn_rsq1(hp.disc, am);
+        if (__builtin_expect(__any(am < 0x1p-96f), 0)) { // |disc| below the fast sequence's range
+            asm volatile("" ::: "memory");
+            q = sqrtf(hp.disc);
+        }
+#else
+        q = sqrtf(hp.disc);
+#endif
+        const float t = select_root(hp.b - q, hp.b + q, ta.eps);
+        if (t < tmin || (t == tmin && (int)k < idx)) { tmin = t; idx = (int)k; }
+    };
+    if (grid_ok)
+        for (uint32_t i = 0; i < h.nlarge; ++i) { const uint32_t k = large[i]; test_large(geom[k], k); } // wave-uniform: scalar loads
+    const float dd = s.dxy.x * s.dxy.x + s.dxy.y * s.dxy.y + s.dz * s.dz;
+    const bool unit = fabsf(dd - 1.0f) <= 1e-3f; // false for NaN/inf
+    if (!grid_ok) {
+        if (!fin)
+            for (uint32_t k = 0; k < ns; ++k) { ++n_tests; test_geom(make_float4(cxp[k], cyp[k], czp[k], r2p[k]), k); }
+    } else if (!fin && !unit) {
+        for (uint32_t k = 0; k < ns; ++k) test(k);
+    } else if (!fin) {
+        // slab test against the grid box; all DDA state in scalars (no indexed arrays -> no scratch)
+        float tn = 0.0f, tf = 3.0e38f;
+        bool inbox = true;
+        // One v_rcp_f32 per axis serves the slab test and the DDA increments (1 ulp is irrelevant here: the
+        // walk's exit test carries 1e-3 relative slack plus the binning margin, and a sphere near a cell corner is
+        // listed in every cell its inflated box touches, whichever of two near-simultaneous crossings comes first).
+        auto recip = [&](float dv) {
+#if defined(__HIP_DEVICE_COMPILE__)
+            return __builtin_amdgcn_rcpf(dv);
+#else
+            return 1.0f / dv;
+#endif
+        };
+        const float ix = recip(s.dxy.x), iy = recip(s.dxy.y), iz = recip(s.dz);
+        auto slab = [&](float o, float dv, float inv, float lo, float hi) {
+            if (fabsf(dv) > 1e-20f) {
+                const float t1 = (lo - o) * inv, t2 = (hi - o) * inv;
+                tn = fmaxf(tn, fminf(t1, t2));
+                tf = fminf(tf, fmaxf(t1, t2));
+            } else if (!(o >= lo && o <= hi)) inbox = false;
+        };
+        slab(s.oxy.x, s.dxy.x, ix, h.gmin[0], h.gmax[0]);
+        slab(s.oxy.y, s.dxy.y, iy, h.gmin[1], h.gmax[1]);
+        slab(s.oz, s.dz, iz, h.gmin[2], h.gmax[2]);
+        if (inbox && tn <= tf) {
+            auto axis = [&](float o, float dv, float inv, float lo, float cellw, float invw, int na, int &c, int &step,
+                            float &tmax, float &tdel) {
+                int ci = (int)floorf((o + dv * tn - lo) * invw);
+                ci = ci < 0 ? 0 : (ci >= na ? na - 1 : ci);
+                c = ci;
+                if (dv > 1e-20f) { step = 1; tmax = (lo + (float)(ci + 1) * cellw - o) * inv; tdel = cellw * inv; }
+                else if (dv < -1e-20f) { step = -1; tmax = (lo + (float)ci * cellw - o) * inv; tdel = -cellw * inv; }
+                else { step = 0; tmax = 3.0e38f; tdel = 3.0e38f; }
+            };
+            int c0, c1, c2, st0, st1, st2;
+            float tm0, tm1, tm2, td0, td1, td2;
+            axis(s.oxy.x, s.dxy.x, ix, h.gmin[0], h.cell[0], h.inv_cell[0], n0, c0, st0, tm0, td0);
+            axis(s.oxy.y, s.dxy.y, iy, h.gmin[1], h.cell[1], h.inv_cell[1], n1, c1, st1, tm1, td1);
+            axis(s.oz, s.dz, iz, h.gmin[2], h.cell[2], h.inv_cell[2], n2, c2, st2, tm2, td2);
+            const int max_steps = n0 + n1 + n2 + 3;
+            uint32_t cell = (uint32_t)((c2 * n1 + c1) * n0 + c0);
+            uint32_t b = cells[cell], e = cells[cell + 1];
+            for (int it = 0; it < max_steps; ++it) {
+                ++n_cells;
+                n_tests += e - b;
+                // Which cell comes next depends on the crossing parameters only, not on what the candidates of
+                // this cell turn out to be: fetch its item range now, so that the dependent load is in flight
+                // while they are tested (the fetch is wasted when the walk ends here).
+                const float te = fminf(tm0, fminf(tm1, tm2)); // parameter at which the ray leaves this cell
+                const bool s0 = tm0 <= tm1 && tm0 <= tm2, s1 = !s0 && tm1 <= tm2, s2 = !s0 && !s1;
+                if (s0) { c0 += st0; tm0 += td0; }
+                if (s1) { c1 += st1; tm1 += td1; }
+                if (s2) { c2 += st2; tm2 += td2; }
+                const bool inside = (unsigned)c0 < (unsigned)n0 && (unsigned)c1 < (unsigned)n1 && (unsigned)c2 < (unsigned)n2;
+                uint32_t nb = 0, ne = 0;
+                if (inside) {
+                    cell = (uint32_t)((c2 * n1 + c1) * n0 + c0);
+                    nb = cells[cell];
+                    ne = cells[cell + 1];
+                }
+                uint32_t i = b;
+                for (; i + 2 <= e; i += 2) { // two candidates per step: their loads are in flight together
+                    const float4 ga = item_geom[i], gb = item_geom[i + 1];
+                    test_item(ga, i);
+                    test_item(gb, i + 1);
+                }
+                if (i < e) test_item(item_geom[i], i);
+                if (tmin < te - (1e-3f * fabsf(te) + h.margin)) break; // nothing nearer can lie ahead
+                if (!inside) break;
+                b = nb;
+                e = ne;
+            }
+        }
+    }
+    if (!fin) {
+        if (pos != ~0u) idx = (int)items[pos];
+        const uint32_t g = (idx < 0) ? ns - 1 : (uint32_t)idx;
+        const float4 gc = grid_ok ? geom[g] : make_float4(cxp[g], cyp[g], czp[g], r2p[g]);
+#if defined(__HIP_DEVICE_COMPILE__)
+        {   // exact fast sqrt / shared-reciprocal divide (pt_core.h); out-of-range operands redo the step with sqrtf() and '/'
+            PathState n = s;
+            float amin = 1.0f;
+            shade_and_reflect<MODE, true>(n, tmin, gc.x, gc.y, gc.z, colx[g], coly[g], colz[g], idx == ta.light, &amin);
+            if (__builtin_expect(__any(amin < 0x1p-96f), 0)) {
+                asm volatile("" ::: "memory");
+                n = s;
+                shade_and_reflect<MODE>(n, tmin, gc.x, gc.y, gc.z, colx[g], coly[g], colz[g], idx == ta.light);
+            }
+            s = n;
+        }
+#else
+        shade_and_reflect<MODE>(s, tmin, gc.x, gc.y, gc.z, colx[g], coly[g], colz[g], idx == ta.light);
+#endif
+    }
+}
+
+template <int MODE, bool RETIRE>
+__device__ __forceinline__ uint32_t trace_grid(const float *__restrict__ sph, const uint32_t *__restrict__ grid,
+                                               PathState &s, bool valid, const TraceArgs &ta, uint64_t path) {
+    const GridCtx gc{reinterpret_cast<const GridHeader *>(grid), sph, grid, &ta};
+    const uint64_t rr_key = ta.rr_start ? rr_path_key(ta.seed, path) : 0;
     uint32_t traced = 0, n_cells = 0, n_tests = 0; // statistics
     for (uint32_t d = 0; d < ta.depth; ++d) {
         const bool fin = !valid || (RETIRE && path_finished(s));
         if (RETIRE && __all(fin)) break;
-        float tmin = kMissT;
-        int idx = (MODE == kModeOracle) ? -1 : 0;
-        auto test_geom = [&](const float4 g, uint32_t k) {
-            const HitPre hp = intersect_pre(g.x, g.y, g.z, g.w, s.oxy.x, s.oxy.y, s.oz, s.dxy.x, s.dxy.y, s.dz);
-            if (hp.disc >= 0.0f) {
-                const float t = intersect_post(hp, ta.eps);
-                if (t < tmin || (t == tmin && (int)k < idx)) { tmin = t; idx = (int)k; }
-            }
-        };
-        auto test = [&](uint32_t k) { ++n_tests; test_geom(geom[k], k); };
-        // A candidate of the walk is identified by its position in the item list; the sphere index (one more
-        // dependent load per candidate) is only fetched when it matters: on an exact tie of t -- mostly the same
-        // sphere met again in the next cell -- and once at the end for the winner.
-        uint32_t pos = ~0u; // item position of the running minimum, ~0u while `idx` itself is authoritative
-        auto test_item = [&](const float4 g, uint32_t i) {
-            const HitPre hp = intersect_pre(g.x, g.y, g.z, g.w, s.oxy.x, s.oxy.y, s.oz, s.dxy.x, s.dxy.y, s.dz);
-            if (hp.disc >= 0.0f) {
-                const float t = intersect_post(hp, ta.eps);
-                if (t < tmin) { tmin = t; pos = i; }
-                else if (t == tmin) {
-                    const int cur = (pos != ~0u) ? (int)items[pos] : idx;
-                    if ((int)items[i] < cur) pos = i;
-                }
-            }
-        };
-        // The large spheres are tested by every lane of the wave and (walls) hit by every ray, so the `disc >= 0`
-        // skip never fires for them: the exact single-rsq sqrt (pt_core.h) instead of sqrtf()'s full expansion.  A
-        // negative discriminant gives NaN roots and select_root's kMissT like the skipped form; +inf gives NaN
-        // instead of +inf, and neither can beat tmin <= kMissT.
-        auto test_large = [&](const float4 g, uint32_t k) {
-            ++n_tests;
-            const HitPre hp = intersect_pre(g.x, g.y, g.z, g.w, s.oxy.x, s.oxy.y, s.oz, s.dxy.x, s.dxy.y, s.dz);
-            float q;
-#if defined(__HIP_DEVICE_COMPILE__) // the sqrt variants are device-only builtins
-            float am = 1.0f;
-            q = sqrt_rn_rsq1(hp.disc, am);
-            if (__builtin_expect(__any(am < 0x1p-96f), 0)) { // |disc| below the fast sequence's range
-                asm volatile("" ::: "memory");
-                q = sqrtf(hp.disc);
-            }
-#else
-            q = sqrtf(hp.disc);
-#endif
-            const float t = select_root(hp.b - q, hp.b + q, ta.eps);
-            if (t < tmin || (t == tmin && (int)k < idx)) { tmin = t; idx = (int)k; }
-        };
-        if (grid_ok)
-            for (uint32_t i = 0; i < h.nlarge; ++i) { const uint32_t k = large[i]; test_large(geom[k], k); } // wave-uniform: scalar loads
-        const float dd = s.dxy.x * s.dxy.x + s.dxy.y * s.dxy.y + s.dz * s.dz;
-        const bool unit = fabsf(dd - 1.0f) <= 1e-3f; // false for NaN/inf
-        if (!grid_ok) {
-            if (!fin)
-                for (uint32_t k = 0; k < ns; ++k) { ++n_tests; test_geom(make_float4(cxp[k], cyp[k], czp[k], r2p[k]), k); }
-        } else if (!fin && !unit) {
-            for (uint32_t k = 0; k < ns; ++k) test(k);
-        } else if (!fin) {
-            // slab test against the grid box; all DDA state in scalars (no indexed arrays -> no scratch)
-            float tn = 0.0f, tf = 3.0e38f;
-            bool inbox = true;
-            // One v_rcp_f32 per axis serves the slab test and the DDA increments (1 ulp is irrelevant here: the
-            // walk's exit test carries 1e-3 relative slack plus the binning margin, and a sphere near a cell corner is
-            // listed in every cell its inflated box touches, whichever of two near-simultaneous crossings comes first).
-            auto recip = [&](float dv) {
-#if defined(__HIP_DEVICE_COMPILE__)
-                return __builtin_amdgcn_rcpf(dv);
-#else
-                return 1.0f / dv;
-#endif
-            };
-            const float ix = recip(s.dxy.x), iy = recip(s.dxy.y), iz = recip(s.dz);
-            auto slab = [&](float o, float dv, float inv, float lo, float hi) {
-                if (fabsf(dv) > 1e-20f) {
-                    const float t1 = (lo - o) * inv, t2 = (hi - o) * inv;
-                    tn = fmaxf(tn, fminf(t1, t2));
-                    tf = fminf(tf, fmaxf(t1, t2));
-                } else if (!(o >= lo && o <= hi)) inbox = false;
-            };
-            slab(s.oxy.x, s.dxy.x, ix, h.gmin[0], h.gmax[0]);
-            slab(s.oxy.y, s.dxy.y, iy, h.gmin[1], h.gmax[1]);
-            slab(s.oz, s.dz, iz, h.gmin[2], h.gmax[2]);
-            if (inbox && tn <= tf) {
-                auto axis = [&](float o, float dv, float inv, float lo, float cellw, float invw, int na, int &c, int &step,
-                                float &tmax, float &tdel) {
-                    int ci = (int)floorf((o + dv * tn - lo) * invw);
-                    ci = ci < 0 ? 0 : (ci >= na ? na - 1 : ci);
-                    c = ci;
-                    if (dv > 1e-20f) { step = 1; tmax = (lo + (float)(ci + 1) * cellw - o) * inv; tdel = cellw * inv; }
-                    else if (dv < -1e-20f) { step = -1; tmax = (lo + (float)ci * cellw - o) * inv; tdel = -cellw * inv; }
-                    else { step = 0; tmax = 3.0e38f; tdel = 3.0e38f; }
-                };
-                int c0, c1, c2, st0, st1, st2;
-                float tm0, tm1, tm2, td0, td1, td2;
-                axis(s.oxy.x, s.dxy.x, ix, h.gmin[0], h.cell[0], h.inv_cell[0], n0, c0, st0, tm0, td0);
-                axis(s.oxy.y, s.dxy.y, iy, h.gmin[1], h.cell[1], h.inv_cell[1], n1, c1, st1, tm1, td1);
-                axis(s.oz, s.dz, iz, h.gmin[2], h.cell[2], h.inv_cell[2], n2, c2, st2, tm2, td2);
-                const int max_steps = n0 + n1 + n2 + 3;
-                uint32_t cell = (uint32_t)((c2 * n1 + c1) * n0 + c0);
-                uint32_t b = cells[cell], e = cells[cell + 1];
-                for (int it = 0; it < max_steps; ++it) {
-                    ++n_cells;
-                    n_tests += e - b;
-                    // Which cell comes next depends on the crossing parameters only, not on what the candidates of
-                    // this cell turn out to be: fetch its item range now, so that the dependent load is in flight
-                    // while they are tested (the fetch is wasted when the walk ends here).
-                    const float te = fminf(tm0, fminf(tm1, tm2)); // parameter at which the ray leaves this cell
-                    const bool s0 = tm0 <= tm1 && tm0 <= tm2, s1 = !s0 && tm1 <= tm2, s2 = !s0 && !s1;
-                    if (s0) { c0 += st0; tm0 += td0; }
-                    if (s1) { c1 += st1; tm1 += td1; }
-                    if (s2) { c2 += st2; tm2 += td2; }
-                    const bool inside = (unsigned)c0 < (unsigned)n0 && (unsigned)c1 < (unsigned)n1 && (unsigned)c2 < (unsigned)n2;
-                    uint32_t nb = 0, ne = 0;
-                    if (inside) {
-                        cell = (uint32_t)((c2 * n1 + c1) * n0 + c0);
-                        nb = cells[cell];
-                        ne = cells[cell + 1];
-                    }
-                    uint32_t i = b;
-                    for (; i + 2 <= e; i += 2) { // two candidates per step: their loads are in flight together
-                        const float4 ga = item_geom[i], gb = item_geom[i + 1];
-                        test_item(ga, i);
-                        test_item(gb, i + 1);
-                    }
-                    if (i < e) test_item(item_geom[i], i);
-                    if (tmin < te - (1e-3f * fabsf(te) + h.margin)) break; // nothing nearer can lie ahead
-                    if (!inside) break;
-                    b = nb;
-                    e = ne;
-                }
-            }
-        }
+        grid_segment<MODE>(gc, s, fin, n_cells, n_tests);
         if (!fin) {
-            if (pos != ~0u) idx = (int)items[pos];
-            const uint32_t g = (idx < 0) ? ns - 1 : (uint32_t)idx;
-            const float4 gc = grid_ok ? geom[g] : make_float4(cxp[g], cyp[g], czp[g], r2p[g]);
-#if defined(__HIP_DEVICE_COMPILE__)
-            {   // exact fast sqrt / shared-reciprocal divide (pt_core.h); out-of-range operands redo the step with sqrtf() and '/'
-                PathState n = s;
-                float amin = 1.0f;
-                shade_and_reflect<MODE, true>(n, tmin, gc.x, gc.y, gc.z, colx[g], coly[g], colz[g], idx == ta.light, &amin);
-                if (__builtin_expect(__any(amin < 0x1p-96f), 0)) {
-                    asm volatile("" ::: "memory");
-                    n = s;
-                    shade_and_reflect<MODE>(n, tmin, gc.x, gc.y, gc.z, colx[g], coly[g], colz[g], idx == ta.light);
-                }
-                s = n;
-            }
-#else
-            shade_and_reflect<MODE>(s, tmin, gc.x, gc.y, gc.z, colx[g], coly[g], colz[g], idx == ta.light);
-#endif
             if (ta.rr_start && d + 1 >= ta.rr_start) russian_roulette(s, rr_key, d);
             ++traced;
         }
     }
-    if (ta.traced) { // statistics: cells visited / candidates tested (per lane, summed over the wave)
-        unsigned long long c = n_cells, t = n_tests;
-        for (int off = 32; off > 0; off >>= 1) { c += __shfl_xor(c, off, 64); t += __shfl_xor(t, off, 64); }
-        if ((threadIdx.x & 63) == 0) { atomicAdd(ta.traced + 1, c); atomicAdd(ta.traced + 2, t); }
-    }
+    grid_stats(ta, n_cells, n_tests);
     return traced;
 }
 
