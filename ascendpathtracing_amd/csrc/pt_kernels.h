@@ -114,7 +114,7 @@ struct FrameArgs {
 // a 3-step butterfly and no shared memory.  GROUP == 1 serves samples < 8 (numpy sums
 // those sequentially).
 template <int MODE, int SC, int GROUP, bool RETIRE>
-__global__ __launch_bounds__(kBlock, (RETIRE && SC == kScene8 && GROUP == 8) ? 4 : (SC == kSceneGrid ? APT_GRID_WAVES : APT_FULL_WAVES)) void render_frame_kernel(const float *__restrict__ sph, FrameArgs fa,
+__global__ __launch_bounds__(kBlock, (RETIRE && SC == kScene8 && GROUP == 8) ? APT_QUEUE_WAVES : (SC == kSceneGrid ? APT_GRID_WAVES : APT_FULL_WAVES)) void render_frame_kernel(const float *__restrict__ sph, FrameArgs fa,
                                                               TraceArgs ta, LeafProg lp) {
     constexpr bool NS8 = SC == kScene8;
     __shared__ float4 tab[16];

@@ -23,6 +23,9 @@ constexpr int kMaxLeaves = 64;   // pairwise-sum leaves -> samples <= 8192
 #define APT_GRID_WAVES 8 // min waves per SIMD requested for the grid-walk kernels: the walk is latency bound
                          // (dependent cell -> item loads), measured 464 / 371 / 334 / 311 / 302 ms at 3 / 4 / 5 / 6 / 8 waves
 #endif
+#ifndef APT_QUEUE_WAVES
+#define APT_QUEUE_WAVES 4 // min waves per SIMD of the 8-sphere frame kernel with the wave-level sample queue (APT_FLAG_RETIRE)
+#endif
 #ifndef APT_FULL_WAVES
 #define APT_FULL_WAVES 6 // min waves per SIMD requested for the full-trace frame kernel: caps it at 80 VGPRs (the scheduler
                          // otherwise interleaves three sphere pairs and lands on 81 -> 5 waves)
