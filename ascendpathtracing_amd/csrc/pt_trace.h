@@ -24,7 +24,7 @@ constexpr int kMaxLeaves = 64;   // pairwise-sum leaves -> samples <= 8192
                          // (dependent cell -> item loads), measured 464 / 371 / 334 / 311 / 302 ms at 3 / 4 / 5 / 6 / 8 waves
 #endif
 #ifndef APT_QUEUE_WAVES
-#define APT_QUEUE_WAVES 4 // min waves per SIMD of the 8-sphere frame kernel with the wave-level sample queue (APT_FLAG_RETIRE)
+#define APT_QUEUE_WAVES 6 // min waves per SIMD of the 8-sphere frame kernel with the wave-level sample queue (APT_FLAG_RETIRE)
 #endif
 #ifndef APT_FULL_WAVES
 #define APT_FULL_WAVES 6 // min waves per SIMD requested for the full-trace frame kernel: caps it at 80 VGPRs (the scheduler
