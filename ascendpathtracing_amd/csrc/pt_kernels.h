@@ -3,6 +3,7 @@
 // RNG and the reference's MT19937 stream), device decode_color, and the arithmetic self-tests.
 #pragma once
 #include "pt_trace.h"
+#include "pt_trace2.h"
 
 namespace {
 
@@ -13,7 +14,7 @@ __global__ __launch_bounds__(kBlock, SC == kSceneGrid ? APT_GRID_WAVES : 1) void
                                                               float *__restrict__ colors, uint64_t n_total,
                                                               uint64_t begin, uint64_t count, TraceArgs ta) {
     constexpr bool NS8 = SC == kScene8;
-    __shared__ float4 tab[16];
+    __shared__ float4 tab[kTab8Floats4];
     __shared__ float4 tile[SC == kSceneTiles ? kTile : 1];
     Scene8 sc;
     Tab8 tab8{tab, tab + 8};
@@ -48,7 +49,7 @@ __global__ __launch_bounds__(kBlock) void render_paths_queue_kernel(const float 
                                                                     const float *__restrict__ sph,
                                                                     float *__restrict__ colors, uint64_t n_total,
                                                                     uint64_t begin, uint64_t count, TraceArgs ta) {
-    __shared__ float4 tab[16];
+    __shared__ float4 tab[kTab8Floats4];
     Scene8 sc;
     const Tab8 tab8 = load_scene8(sph, sc, tab);
     const Gain3 gain = load_gain(sph, ta);
@@ -113,11 +114,13 @@ struct FrameArgs {
 // r[j] (samples j, 8+j, 16+j, ...), so the summation order of np.mean is reproduced with
 // a 3-step butterfly and no shared memory.  GROUP == 1 serves samples < 8 (numpy sums
 // those sequentially).
-template <int MODE, int SC, int GROUP, bool RETIRE>
-__global__ __launch_bounds__(kBlock, (RETIRE && SC == kScene8 && GROUP == 8) ? APT_QUEUE_WAVES : (SC == kSceneGrid ? APT_GRID_WAVES : APT_FULL_WAVES)) void render_frame_kernel(const float *__restrict__ sph, FrameArgs fa,
+// TWO: two samples of a lane's chain are traced at a time (pt_trace2.h); only with SC == kScene8, GROUP == 8, no
+// retirement, no roulette (the host picks the kernel).
+template <int MODE, int SC, int GROUP, bool RETIRE, bool TWO = false>
+__global__ __launch_bounds__(kBlock, TWO ? APT_TWO_WAVES : (RETIRE && SC == kScene8 && GROUP == 8) ? APT_QUEUE_WAVES : (SC == kSceneGrid ? APT_GRID_WAVES : APT_FULL_WAVES)) void render_frame_kernel(const float *__restrict__ sph, FrameArgs fa,
                                                               TraceArgs ta, LeafProg lp) {
     constexpr bool NS8 = SC == kScene8;
-    __shared__ float4 tab[16];
+    __shared__ float4 tab[kTab8Floats4];
     __shared__ float4 tile[SC == kSceneTiles ? kTile : 1];
     extern __shared__ float dyn_lds[];
     float *stack_lds = dyn_lds;                                            // [kMaxStack][3][kStackSlots] when lp.nleaves > 1
@@ -161,6 +164,24 @@ __global__ __launch_bounds__(kBlock, (RETIRE && SC == kScene8 && GROUP == 8) ? A
         return Col{s.rxy.x * gain.r, s.rxy.y * gain.g, s.rz * gain.b};
     };
     auto add = [](const Col &a, const Col &b) { return Col{a.r + b.r, a.g + b.g, a.b + b.b}; };
+    struct Col2 { Col a, b; };
+    auto sample2 = [&](uint32_t ka, uint32_t kb) -> Col2 { // samples ka and kb of this lane's sub-pixel, traced together
+        PathPair pp;
+        {
+            double u1, u2;
+            float rox, roy, roz, rdx, rdy, rdz;
+            path_uniforms(fa.seed, pbase + ka, u1, u2);
+            camera_ray(cam, fa.width, fa.height, pi, pj, sy, sx, u1, u2, rox, roy, roz, rdx, rdy, rdz);
+            pp.ox.x = rox; pp.oy.x = roy; pp.oz.x = roz; pp.dx.x = rdx; pp.dy.x = rdy; pp.dz.x = rdz;
+            path_uniforms(fa.seed, pbase + kb, u1, u2);
+            camera_ray(cam, fa.width, fa.height, pi, pj, sy, sx, u1, u2, rox, roy, roz, rdx, rdy, rdz);
+            pp.ox.y = rox; pp.oy.y = roy; pp.oz.y = roz; pp.dx.y = rdx; pp.dy.y = rdy; pp.dz.y = rdz;
+        }
+        pp.rx = pp.ry = pp.rz = f2{1.0f, 1.0f};
+        trace2_ns8<MODE>(sc, tab8, pp, ta);
+        traced += 2 * ta.depth;
+        return Col2{Col{pp.rx.x * gain.r, pp.ry.x * gain.g, pp.rz.x * gain.b}, Col{pp.rx.y * gain.r, pp.ry.y * gain.g, pp.rz.y * gain.b}};
+    };
 
     float res[3] = {0.0f, 0.0f, 0.0f};
     uint32_t start = 0;
@@ -282,8 +303,21 @@ __global__ __launch_bounds__(kBlock, (RETIRE && SC == kScene8 && GROUP == 8) ? A
                     atomicAdd(ta.traced + 2, 64ull * n_gen_exec);
                 }
             } else {
-                Col a = sample(start + j);
-                for (uint32_t i8 = 8; i8 < nfull; i8 += 8) a = add(a, sample(start + i8 + j));
+                Col a;
+                uint32_t i8;
+                if (TWO && nfull >= 16) { // numpy's chain r[j] += a[j + 8m], two members at a time, added in order
+                    Col2 c = sample2(start + j, start + 8 + j);
+                    a = add(c.a, c.b);
+                    for (i8 = 16; i8 + 16 <= nfull; i8 += 16) {
+                        c = sample2(start + i8 + j, start + i8 + 8 + j);
+                        a = add(a, c.a);
+                        a = add(a, c.b);
+                    }
+                } else {
+                    a = sample(start + j);
+                    i8 = 8;
+                }
+                for (; i8 < nfull; i8 += 8) a = add(a, sample(start + i8 + j));
                 acc[0] = a.r; acc[1] = a.g; acc[2] = a.b;
             }
 #pragma unroll

@@ -23,6 +23,9 @@ constexpr int kMaxLeaves = 64;   // pairwise-sum leaves -> samples <= 8192
 #define APT_GRID_WAVES 8 // min waves per SIMD requested for the grid-walk kernels: the walk is latency bound
                          // (dependent cell -> item loads), measured 464 / 371 / 334 / 311 / 302 ms at 3 / 4 / 5 / 6 / 8 waves
 #endif
+#ifndef APT_TWO_WAVES
+#define APT_TWO_WAVES 4 // min waves per SIMD of the two-paths-per-lane frame kernel (pt_trace2.h): twice the path state
+#endif
 #ifndef APT_QUEUE_WAVES
 #define APT_QUEUE_WAVES 6 // min waves per SIMD of the 8-sphere frame kernel with the wave-level sample queue (APT_FLAG_RETIRE)
 #endif
@@ -41,7 +44,7 @@ struct Scene8 { // wave-uniform registers (SGPRs)
 // LDS table of the 8-sphere scene: entry k of `geo` = (cx, cy, cz, r2), entry k of `alb` = (albedo, 0); 16 bytes per
 // entry, so that the byte offsets of entry k's index bits (16, 32, 64) are inline constants (bounce_ns8_v2).
 struct Tab8 { const float4 *geo, *alb; };
-constexpr int kTab8Floats4 = 16;
+constexpr int kTab8Floats4 = 17; // 8 geometry + 8 albedo entries + (1,1,1)
 
 struct TraceArgs {
     uint32_t ns;
@@ -207,16 +210,18 @@ __device__ __forceinline__ void apply_albedo(f2 &rxy, float &rz, const Albedo &a
                  : "scc");   // s_and_saveexec writes SCC: the compiler must not keep a scalar compare alive across this
 }
 
+// The intersection half of a bounce: all 8 spheres against one ray, integer-key arg-min, -> nearest accepted root,
+// byte offset of the hit sphere's LDS table entry (index * 16) and the wave mask of the lanes that hit the light.
+struct Hit8 { float tmin; uint32_t addr; uint64_t light; };
 template <int MODE>
-__device__ __forceinline__ uint64_t bounce_ns8_v2(const Scene8 &sc, const Tab8 tab, const PathState &s, PathState &n,
-                                                  const TraceArgs &ta, const KeyConsts &kc, uint64_t &alive, Albedo &albedo) {
-    float amin = 1.0f;
+__device__ __forceinline__ Hit8 intersect_ns8_v2(const Scene8 &sc, float ox, float oy, float oz, float dx, float dy, float dz,
+                                                 const TraceArgs &ta, const KeyConsts &kc, float &amin) {
     uint32_t best = kc.init;
     uint64_t b0 = 0, b1 = 0, b2 = 0, any = 0;
 #ifdef APT_T_EXTRA // measurement only (profiles/microbench/insitu_costs.sh): N extra independent instructions of one class per bounce
     {
-        float x0 = s.oxy.x, x1 = s.oxy.y, x2 = s.oz, x3 = s.dxy.x;
-        f2 y0 = {s.oxy.x, s.oxy.y}, y1 = {s.oz, s.dxy.x};
+        float x0 = ox, x1 = oy, x2 = oz, x3 = dx;
+        f2 y0 = {ox, oy}, y1 = {oz, dx};
 #define APT_R4(a) a a a a
 #if APT_T_EXTRA == 1   // 16 plain
 #define APT_T_OPS "v_add_f32 %0, %0, %6\n v_add_f32 %1, %1, %6\n v_add_f32 %2, %2, %7\n v_add_f32 %3, %3, %7\n"
@@ -227,7 +232,7 @@ __device__ __forceinline__ uint64_t bounce_ns8_v2(const Scene8 &sc, const Tab8 t
 #else                  // 4 transcendental
 #define APT_T_OPS "v_rsq_f32 %0, %0\n"
 #endif
-        asm volatile(APT_R4(APT_T_OPS) : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(y0), "+v"(y1) : "v"(s.dxy.y), "v"(s.dz));
+        asm volatile(APT_R4(APT_T_OPS) : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(y0), "+v"(y1) : "v"(dy), "v"(dz));
     }
 #endif
     auto update = [&](float t0, float t1, int k) {
@@ -243,7 +248,7 @@ __device__ __forceinline__ uint64_t bounce_ns8_v2(const Scene8 &sc, const Tab8 t
 #pragma unroll
     for (int k = 0; k < 8; k += 2) { // rt_helper.h:457-467, two spheres per packed instruction
         const HitPre2 h = intersect_pre2(f2{sc.cx[k], sc.cx[k + 1]}, f2{sc.cy[k], sc.cy[k + 1]}, f2{sc.cz[k], sc.cz[k + 1]},
-                                         f2{sc.r2[k], sc.r2[k + 1]}, s.oxy.x, s.oxy.y, s.oz, s.dxy.x, s.dxy.y, s.dz);
+                                         f2{sc.r2[k], sc.r2[k + 1]}, ox, oy, oz, dx, dy, dz);
         amin = min3_abs(amin, h.disc.x, h.disc.y);
         // sqrt_rn_rsq1 on both lanes of the pair (pt_core.h): y = x*r, hh = r/2, q = fma(fma(-y,y,x), hh, y)
         const f2 r0 = {__builtin_amdgcn_rsqf(h.disc.x), __builtin_amdgcn_rsqf(h.disc.y)};
@@ -266,6 +271,17 @@ __device__ __forceinline__ uint64_t bounce_ns8_v2(const Scene8 &sc, const Tab8 t
     }
     light_mask = __builtin_amdgcn_ballot_w64(addr == (uint32_t)ta.light * 16u); // light < 0 or > 7 never matches
     if (MODE == kModeOracle) light_mask &= any;
+    return Hit8{tmin, addr, light_mask};
+}
+
+template <int MODE>
+__device__ __forceinline__ uint64_t bounce_ns8_v2(const Scene8 &sc, const Tab8 tab, const PathState &s, PathState &n,
+                                                  const TraceArgs &ta, const KeyConsts &kc, uint64_t &alive, Albedo &albedo) {
+    float amin = 1.0f;
+    const Hit8 hit = intersect_ns8_v2<MODE>(sc, s.oxy.x, s.oxy.y, s.oz, s.dxy.x, s.dxy.y, s.dz, ta, kc, amin);
+    const float tmin = hit.tmin;
+    const uint32_t addr = hit.addr;
+    const uint64_t light_mask = hit.light;
     const float4 c = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(tab.geo) + addr);
     const float4 col = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(tab.alb) + addr);
     // GenerateNewRays (rt_helper.h:504-709), as shade_and_reflect<MODE, true>, with the x and y components of
@@ -742,6 +758,7 @@ __device__ __forceinline__ Tab8 load_scene8(const float *__restrict__ sph, Scene
         tab[k] = make_float4(sph[8 + k], sph[16 + k], sph[24 + k], sph[k]);
         tab[8 + k] = make_float4(sph[56 + k], sph[64 + k], sph[72 + k], 0.0f);
     }
+    if (threadIdx.x == 8) tab[16] = make_float4(1.0f, 1.0f, 1.0f, 0.0f); // "albedo" of a path that is no longer alive (pt_trace2.h)
     __syncthreads();
     return Tab8{tab, tab + 8};
 }

@@ -1,0 +1,164 @@
+// pt_trace2.h -- TWO paths per lane for the full-trace 8-sphere frame kernel (included by pt_kernels.h).
+//
+// In this kernel a VALU instruction costs one ~4-cycle issue slot whatever it does (profiles/microbench/
+// issue_model_mi355x.txt), so the bounce costs its instruction COUNT and a packed
+// v_pk_*_f32 is two operations for one slot.  The intersections are already packed (two spheres per
+// instruction); the shading step of ONE path only fills the second half for the x/y components.  With two
+// paths A and B in a lane, every register pair holds (A, B) of one quantity and the whole shading step runs
+// packed: 36 instead of 48 instructions per path and bounce.  The intersections stay as they are -- eight
+// spheres in four packed pairs per path, reading ray component A or B out of its pair through op_sel (free) --
+// and run for A, then for B, so the scalar arg-min masks of A are consumed before B needs the registers.
+//
+// Same arithmetic as bounce_ns8_v2 (pt_trace.h), operation for operation: v_pk_{add,mul,fma}_f32 round each half
+// like the scalar instruction.  Used for the frame kernel without APT_FLAG_RETIRE and APT_FLAG_RR only.
+#pragma once
+#include "pt_trace.h"
+
+namespace {
+
+struct PathPair { // .x = path A, .y = path B
+    f2 ox, oy, oz, dx, dy, dz; // rays
+    f2 rx, ry, rz;             // throughputs
+};
+
+__device__ __forceinline__ PathState unpack_path(const PathPair &p, int which, uint64_t alive) {
+    PathState s;
+    if (which == 0) path_init(s, p.ox.x, p.oy.x, p.oz.x, p.dx.x, p.dy.x, p.dz.x);
+    else path_init(s, p.ox.y, p.oy.y, p.oz.y, p.dx.y, p.dy.y, p.dz.y);
+    s.rxy = which == 0 ? f2{p.rx.x, p.ry.x} : f2{p.rx.y, p.ry.y};
+    s.rz = which == 0 ? p.rz.x : p.rz.y;
+    s.alive = select_const(alive, 1);
+    return s;
+}
+
+// float32(sum in float64 of three float32 products): np.dot / np.linalg.norm of the NumPy oracle (gen_data.py:347,349)
+__device__ __forceinline__ float sum3_f64(float p0, float p1, float p2) {
+    double acc = 0.0 + (double)p0;
+    acc = acc + (double)p1;
+    acc = acc + (double)p2;
+    return (float)acc;
+}
+
+// One bounce of both paths.  aliveA / aliveB: wave masks (in: before, out: after).  redoA / redoB: wave masks of
+// the lanes whose path A / B left the validity range of the fast sequences.  `ones_off`: byte offset, relative to the albedo
+// table, of an entry (1, 1, 1) -- a path that is no longer alive multiplies its throughput by it (x1 is exact).
+template <int MODE>
+__device__ __forceinline__ void bounce2_ns8(const Scene8 &sc, const Tab8 tab, const PathPair &s, PathPair &n,
+                                            const TraceArgs &ta, const KeyConsts &kc, uint32_t ones_off,
+                                            uint64_t &aliveA, uint64_t &aliveB, uint64_t &redoA, uint64_t &redoB) {
+    float aminA = 1.0f, aminB = 1.0f; // per path: a finished path's request for the exact form can be ignored (trace2_ns8)
+    const Hit8 hA = intersect_ns8_v2<MODE>(sc, s.ox.x, s.oy.x, s.oz.x, s.dx.x, s.dy.x, s.dz.x, ta, kc, aminA);
+    const Hit8 hB = intersect_ns8_v2<MODE>(sc, s.ox.y, s.oy.y, s.oz.y, s.dx.y, s.dy.y, s.dz.y, ta, kc, aminB);
+    aliveA &= ~hA.light;                    // rt_helper.h:773-787  alive &= idx != light
+    aliveB &= ~hB.light;
+    // centre and albedo of the two hit spheres: dword reads from the LDS table straight into (A, B) pairs
+    const char *geo = reinterpret_cast<const char *>(tab.geo), *alb = reinterpret_cast<const char *>(tab.alb);
+    auto ld = [](const char *base, uint32_t off) { return *reinterpret_cast<const float *>(base + off); };
+    uint32_t cA, cB; // albedo entry, or the (1,1,1) entry once the path is not alive (rt_helper.h:799-810: ret *= alive ? albedo : 1)
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(cA) : "v"(ones_off), "v"(hA.addr), "s"(aliveA));
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(cB) : "v"(ones_off), "v"(hB.addr), "s"(aliveB));
+    const f2 cx = {ld(geo, hA.addr), ld(geo, hB.addr)}, cy = {ld(geo, hA.addr + 4), ld(geo, hB.addr + 4)},
+             cz = {ld(geo, hA.addr + 8), ld(geo, hB.addr + 8)};
+    const f2 ax = {ld(alb, cA), ld(alb, cB)}, ay = {ld(alb, cA + 4), ld(alb, cB + 4)}, az = {ld(alb, cA + 8), ld(alb, cB + 8)};
+    // GenerateNewRays, rt_helper.h:504-709 (see bounce_ns8_v2 for the single-path form)
+    const f2 t = {hA.tmin, hB.tmin};
+    const f2 hx = s.ox + s.dx * t, hy = s.oy + s.dy * t, hz = s.oz + s.dz * t;   // :513-518
+    const f2 nx = hx - cx, ny = hy - cy, nz = hz - cz;                            // :635-637
+    f2 len2;
+    if (MODE == kModeOracle) {
+        const f2 p0 = nx * nx, p1 = ny * ny, p2 = nz * nz;
+        len2 = f2{sum3_f64(p0.x, p1.x, p2.x), sum3_f64(p0.y, p1.y, p2.y)};
+    } else {
+        len2 = nx * nx + ny * ny;                                                  // :641-649 (0 + x^2 is x^2)
+        len2 = len2 + nz * nz;
+    }
+    aminA = min3_abs(aminA, len2.x, nx.x);      // validity of the fast sqrt / divide sequences (pt_core.h)
+    aminA = min3_abs(aminA, ny.x, nz.x);
+    aminB = min3_abs(aminB, len2.y, nx.y);
+    aminB = min3_abs(aminB, ny.y, nz.y);
+    f2 L;
+    {   // sqrt_rn_rsq1 on both paths
+        const f2 r0 = {__builtin_amdgcn_rsqf(len2.x), __builtin_amdgcn_rsqf(len2.y)};
+        const f2 y = len2 * r0, h = r0 * 0.5f;
+        const f2 r = __builtin_elementwise_fma(-y, y, len2);
+        L = __builtin_elementwise_fma(r, h, y);
+    }
+    f2 ux, uy, uz;
+    {   // div3_packed's sequence (pt_core.h) with (A, B) in the halves: one refined reciprocal per path, three quotients
+        const f2 r0 = {__builtin_amdgcn_rcpf(L.x), __builtin_amdgcn_rcpf(L.y)};
+        const f2 one = {1.0f, 1.0f};
+        const f2 e0 = __builtin_elementwise_fma(-L, r0, one);
+        const f2 r = __builtin_elementwise_fma(e0, r0, r0);
+        auto quot = [&](const f2 num) {
+            f2 q = num * r;
+            f2 e = __builtin_elementwise_fma(-L, q, num);
+            q = __builtin_elementwise_fma(e, r, q);
+            e = __builtin_elementwise_fma(-L, q, num);
+            return __builtin_elementwise_fma(e, r, q);
+        };
+        ux = quot(nx); uy = quot(ny); uz = quot(nz);
+    }
+    f2 dot;
+    if (MODE == kModeOracle) {
+        const f2 p0 = s.dx * ux, p1 = s.dy * uy, p2 = s.dz * uz;
+        dot = f2{sum3_f64(p0.x, p1.x, p2.x), sum3_f64(p0.y, p1.y, p2.y)};
+    } else {
+        const f2 zero = {0.0f, 0.0f};
+        dot = zero + s.dx * ux;                                                    // :690 Duplicate(0), :694-696
+        dot = dot + s.dy * uy;
+        dot = dot + s.dz * uz;
+    }
+    const f2 k2 = dot * 2.0f;                                                      // :697
+    n.dx = s.dx - ux * k2; n.dy = s.dy - uy * k2; n.dz = s.dz - uz * k2;           // :699-704
+    n.ox = hx; n.oy = hy; n.oz = hz;                                               // :706-708
+    n.rx = ax * s.rx; n.ry = ay * s.ry; n.rz = az * s.rz;                          // :804-810 (albedo or 1)
+    redoA = __builtin_amdgcn_ballot_w64(aminA < 0x1p-96f) | __builtin_amdgcn_ballot_w64(f32_bits(len2.x) > 0x5d800000u); // len2 > 2^60 or NaN:
+    redoB = __builtin_amdgcn_ballot_w64(aminB < 0x1p-96f) | __builtin_amdgcn_ballot_w64(f32_bits(len2.y) > 0x5d800000u); // see div3_shared
+}
+
+// All bounces of both paths (full trace: no retirement, no roulette).  The hot loop has no merge with the exact
+// form and no state copies (two bounces per turn, ping-pong): see trace_ns8.
+template <int MODE>
+__device__ __forceinline__ void trace2_ns8(const Scene8 &sc, const Tab8 tab, PathPair &s, const TraceArgs &ta) {
+    const KeyConsts kc = make_key_consts(ta.eps);
+    uint32_t ones_off = 8 * 16; // the entry after the 8 albedos (load_scene8 writes it)
+    asm volatile("" : "+v"(ones_off));
+    uint64_t aliveA = __builtin_amdgcn_ballot_w64(true), aliveB = aliveA;
+    auto rest_exact = [&](const PathPair &from, uint32_t d0) { // -> result in s
+        PathState a = unpack_path(from, 0, aliveA), b = unpack_path(from, 1, aliveB);
+        for (uint32_t d = d0; d < ta.depth; ++d) {
+            PathState na, nb;
+            (void)bounce_ns8<MODE, false>(sc, tab, a, na, ta);
+            (void)bounce_ns8<MODE, false>(sc, tab, b, nb, ta);
+            a = na; b = nb;
+        }
+        if (ta.traced && (threadIdx.x & 63) == 0) atomicAdd(ta.traced + 3, 1ull); // statistics: waves that left the fast loop
+        s.rx = f2{a.rxy.x, b.rxy.x}; s.ry = f2{a.rxy.y, b.rxy.y}; s.rz = f2{a.rz, b.rz};
+    };
+    auto step = [&](const PathPair &in, PathPair &out) -> bool { // true: the wave must go exact from `in`
+        uint64_t oa = aliveA, ob = aliveB, redoA, redoB;
+        bounce2_ns8<MODE>(sc, tab, in, out, ta, kc, ones_off, oa, ob, redoA, redoB);
+        if (__builtin_expect((redoA | redoB) != 0, 0)) {
+            // the request of a path that is already finished (alive bit cleared or throughput zero) is ignored: it cannot
+            // reach any output any more (deep all-miss paths, |n| ~ 1e20, are of that kind)
+            const bool finA = select_const(aliveA, 1) == 0 || (in.rx.x == 0.0f && in.ry.x == 0.0f && in.rz.x == 0.0f);
+            const bool finB = select_const(aliveB, 1) == 0 || (in.rx.y == 0.0f && in.ry.y == 0.0f && in.rz.y == 0.0f);
+            if (__any((select_const(redoA, 1) != 0 && !finA) || (select_const(redoB, 1) != 0 && !finB))) return true;
+        }
+        aliveA = oa; aliveB = ob;
+        return false;
+    };
+    if (__builtin_expect(!eps_allows_rootkey(ta.eps), 0)) { rest_exact(s, 0); return; }
+    PathPair n;
+    uint32_t d = 0;
+    for (; d + 2 <= ta.depth; d += 2) { // render.cpp:140-188
+        if (__builtin_expect(step(s, n), 0)) { rest_exact(s, d); return; }
+        if (__builtin_expect(step(n, s), 0)) { rest_exact(n, d + 1); return; }
+    }
+    if (d < ta.depth) {
+        if (__builtin_expect(step(s, n), 0)) { rest_exact(s, d); return; }
+        s = n;
+    }
+}
+
+} // namespace

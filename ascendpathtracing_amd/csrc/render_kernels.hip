@@ -92,6 +92,11 @@ void launch_frame(bool retire, dim3 grid, size_t lds, hipStream_t st, const floa
 template <int MODE, int SC>
 void launch_frame_g(int group, bool retire, dim3 grid, size_t lds, hipStream_t st, const float *sph,
                     const FrameArgs &fa, const TraceArgs &ta, const LeafProg &lp) {
+    // the headline case -- 8 spheres, >= 16 samples, every segment traced, no roulette -- runs two paths per lane
+    if (SC == kScene8 && group == 8 && !retire && ta.rr_start == 0 && fa.samples >= 16) {
+        hipLaunchKernelGGL((render_frame_kernel<MODE, kScene8, 8, false, true>), grid, dim3(kBlock), lds, st, sph, fa, ta, lp);
+        return;
+    }
     if (group == 8) launch_frame<MODE, SC, 8>(retire, grid, lds, st, sph, fa, ta, lp);
     else launch_frame<MODE, SC, 1>(retire, grid, lds, st, sph, fa, ta, lp);
 }
