@@ -237,62 +237,31 @@ int apt_build_grid_host(const float *sph, uint32_t ns, void *grid, size_t *out_b
     if (!sph || ns == 0 || !out_bytes) return set_error(APT_ERR_ARG, "apt_build_grid_host: spheres/out_bytes must be non-null, num_spheres non-zero%s");
     const float *r2 = sph, *cx = sph + ns, *cy = sph + 2 * (size_t)ns, *cz = sph + 3 * (size_t)ns;
     std::vector<float> rad(ns);
-    for (uint32_t k = 0; k < ns; ++k) rad[k] = std::sqrt(std::max(r2[k], 0.0f));
+    for (uint32_t k = 0; k < ns; ++k) rad[k] = apt::grid_radius(r2[k]);
     std::vector<float> sorted(rad);
     std::nth_element(sorted.begin(), sorted.begin() + ns / 2, sorted.end());
     const float median = sorted[ns / 2];
     std::vector<uint32_t> large, small;
-    for (uint32_t k = 0; k < ns; ++k) {
-        const bool finite = std::isfinite(rad[k]) && std::isfinite(cx[k]) && std::isfinite(cy[k]) && std::isfinite(cz[k]);
-        if (!finite || rad[k] > 8.0f * median || !(r2[k] >= 0.0f)) large.push_back(k); else small.push_back(k);
+    for (uint32_t k = 0; k < ns; ++k)
+        (apt::grid_is_large(r2[k], cx[k], cy[k], cz[k], rad[k], median) ? large : small).push_back(k);
+    float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f}, scale = 1.0f;
+    for (uint32_t k : small) {
+        const float c[3] = {cx[k], cy[k], cz[k]};
+        for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], c[a] - rad[k]); hi[a] = std::max(hi[a], c[a] + rad[k]); scale = std::max(scale, std::fabs(c[a]) + rad[k]); }
     }
-    apt::GridHeader h;
-    memset(&h, 0, sizeof h);
-    h.magic = apt::kGridMagic; h.num_spheres = ns; h.nlarge = (uint32_t)large.size();
-    float lo[3] = {0, 0, 0}, hi[3] = {1, 1, 1}, scale = 1.0f;
-    if (!small.empty()) {
-        for (int a = 0; a < 3; ++a) { lo[a] = 3.0e38f; hi[a] = -3.0e38f; }
-        for (uint32_t k : small) {
-            const float c[3] = {cx[k], cy[k], cz[k]};
-            for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], c[a] - rad[k]); hi[a] = std::max(hi[a], c[a] + rad[k]); scale = std::max(scale, std::fabs(c[a]) + rad[k]); }
-        }
-    }
-    h.margin = 0.05f + 1e-4f * scale;
-    for (int a = 0; a < 3; ++a) { lo[a] -= 2 * h.margin; hi[a] += 2 * h.margin; }
-    const double vol = (double)(hi[0] - lo[0]) * (hi[1] - lo[1]) * (hi[2] - lo[2]);
     double per_cell = 1.0; // sphere centres per cell (boxes overlap ~4 cells each); measured 74.4 / 70.7 / 70.3 / 70.8 / 72.2 ms at 2 / 1 / 0.7 / 0.5 / 0.35
     if (const char *e = getenv("APT_GRID_SPHERES_PER_CELL")) { const double v = atof(e); if (v > 0.01 && v < 1e6) per_cell = v; }
-    const double target = std::max(1.0, (double)small.size() / per_cell);
-    const double edge = std::cbrt(std::max(vol, 1e-30) / target);
-    for (int a = 0; a < 3; ++a) {
-        const double n = std::ceil((hi[a] - lo[a]) / std::max(edge, 1e-30));
-        h.n[a] = (uint32_t)std::min(128.0, std::max(1.0, n));
-        h.gmin[a] = lo[a]; h.gmax[a] = hi[a];
-        h.cell[a] = (hi[a] - lo[a]) / (float)h.n[a];
-        h.inv_cell[a] = 1.0f / h.cell[a];
-    }
-    h.ncells = h.n[0] * h.n[1] * h.n[2];
-    auto cell_range = [&](uint32_t k, int a, uint32_t &c0, uint32_t &c1) {
-        const float c[3] = {cx[k], cy[k], cz[k]};
-        const float a0 = (c[a] - rad[k] - h.margin - h.gmin[a]) * h.inv_cell[a], a1 = (c[a] + rad[k] + h.margin - h.gmin[a]) * h.inv_cell[a];
-        c0 = (uint32_t)std::min<double>(h.n[a] - 1, std::max(0.0, std::floor((double)a0)));
-        c1 = (uint32_t)std::min<double>(h.n[a] - 1, std::max(0.0, std::floor((double)a1)));
-    };
+    apt::GridHeader h;
+    apt::grid_header_from_stats(ns, (uint32_t)small.size(), (uint32_t)large.size(), lo, hi, scale, per_cell, h);
     std::vector<uint32_t> count(h.ncells + 1, 0);
     for (uint32_t k : small) {
         uint32_t x0, x1, y0, y1, z0, z1;
-        cell_range(k, 0, x0, x1); cell_range(k, 1, y0, y1); cell_range(k, 2, z0, z1);
+        apt::grid_cell_range(h, cx[k], rad[k], 0, x0, x1); apt::grid_cell_range(h, cy[k], rad[k], 1, y0, y1); apt::grid_cell_range(h, cz[k], rad[k], 2, z0, z1);
         for (uint32_t z = z0; z <= z1; ++z) for (uint32_t y = y0; y <= y1; ++y) for (uint32_t x = x0; x <= x1; ++x)
             ++count[(z * h.n[1] + y) * h.n[0] + x + 1];
     }
     for (uint32_t c = 0; c < h.ncells; ++c) count[c + 1] += count[c];
-    h.nitems = count[h.ncells];
-    h.off_large = (uint32_t)(sizeof(apt::GridHeader) / 4);
-    h.off_cells = h.off_large + h.nlarge;
-    h.off_items = h.off_cells + h.ncells + 1;
-    h.off_geom = (h.off_items + h.nitems + 3u) & ~3u;                               // 16-byte aligned float4s
-    h.off_item_geom = h.off_geom + 4 * ns;
-    const size_t words = (size_t)h.off_item_geom + 4 * (size_t)h.nitems;
+    const size_t words = apt::grid_header_offsets(h, count[h.ncells]);
     *out_bytes = words * 4;
     if (!grid) return APT_OK;
     uint32_t *w = (uint32_t *)grid;
@@ -303,7 +272,7 @@ int apt_build_grid_host(const float *sph, uint32_t ns, void *grid, size_t *out_b
     std::vector<uint32_t> cursor(count.begin(), count.end() - 1);
     for (uint32_t k : small) {                                                       // ascending sphere index inside a cell
         uint32_t x0, x1, y0, y1, z0, z1;
-        cell_range(k, 0, x0, x1); cell_range(k, 1, y0, y1); cell_range(k, 2, z0, z1);
+        apt::grid_cell_range(h, cx[k], rad[k], 0, x0, x1); apt::grid_cell_range(h, cy[k], rad[k], 1, y0, y1); apt::grid_cell_range(h, cz[k], rad[k], 2, z0, z1);
         for (uint32_t z = z0; z <= z1; ++z) for (uint32_t y = y0; y <= y1; ++y) for (uint32_t x = x0; x <= x1; ++x)
             w[h.off_items + cursor[(z * h.n[1] + y) * h.n[0] + x]++] = k;
     }

@@ -613,6 +613,60 @@ struct GridHeader {
     uint32_t pad[2];
 };
 constexpr uint32_t kGridMagic = 0x47524944u; // "GRID"
+constexpr uint32_t kGridMaxCellsPerAxis = 512;  // round 1 capped the grid at 128 cells per axis
+
+// The header of the grid from the statistics of the scene's small spheres (host arithmetic, shared by apt_build_grid_host
+// and apt_build_grid_device so that both produce the same bytes): lo/hi = bounding box of the small spheres' own boxes,
+// scale = max(|centre| + radius, 1).  Cells are sized for ~per_cell sphere centres each.  Offsets that depend on the
+// item count are filled in by grid_header_offsets() once it is known.
+inline void grid_header_from_stats(uint32_t ns, uint32_t nsmall, uint32_t nlarge, const float lo_in[3], const float hi_in[3],
+                                   float scale, double per_cell, GridHeader &h) {
+    memset(&h, 0, sizeof h);
+    h.magic = kGridMagic; h.num_spheres = ns; h.nlarge = nlarge;
+    float lo[3] = {0, 0, 0}, hi[3] = {1, 1, 1};
+    if (nsmall) for (int a = 0; a < 3; ++a) { lo[a] = lo_in[a]; hi[a] = hi_in[a]; }
+    else scale = 1.0f;
+    h.margin = 0.05f + 1e-4f * scale;
+    for (int a = 0; a < 3; ++a) { lo[a] -= 2 * h.margin; hi[a] += 2 * h.margin; }
+    const double vol = (double)(hi[0] - lo[0]) * (hi[1] - lo[1]) * (hi[2] - lo[2]);
+    const double target = fmax(1.0, (double)nsmall / per_cell);
+    const double edge = cbrt(fmax(vol, 1e-30) / target);
+    for (int a = 0; a < 3; ++a) {
+        const double n = ceil((hi[a] - lo[a]) / fmax(edge, 1e-30));
+        h.n[a] = (uint32_t)fmin((double)kGridMaxCellsPerAxis, fmax(1.0, n));
+        h.gmin[a] = lo[a]; h.gmax[a] = hi[a];
+        h.cell[a] = (hi[a] - lo[a]) / (float)h.n[a];
+        h.inv_cell[a] = 1.0f / h.cell[a];
+    }
+    h.ncells = h.n[0] * h.n[1] * h.n[2];
+}
+inline size_t grid_header_offsets(GridHeader &h, uint32_t nitems) { // -> total words
+    h.nitems = nitems;
+    h.off_large = (uint32_t)(sizeof(GridHeader) / 4);
+    h.off_cells = h.off_large + h.nlarge;
+    h.off_items = h.off_cells + h.ncells + 1;
+    h.off_geom = (h.off_items + h.nitems + 3u) & ~3u;                               // 16-byte aligned float4s
+    h.off_item_geom = h.off_geom + 4 * h.num_spheres;
+    return (size_t)h.off_item_geom + 4 * (size_t)h.nitems;
+}
+// cells [c0, c1] of axis a that the box of a small sphere (centre c, radius rad), inflated by the margin, touches
+APT_HD void grid_cell_range(const GridHeader &h, float c, float rad, int a, uint32_t &c0, uint32_t &c1) {
+    const float a0 = (c - rad - h.margin - h.gmin[a]) * h.inv_cell[a], a1 = (c + rad + h.margin - h.gmin[a]) * h.inv_cell[a];
+    const double hi = (double)h.n[a] - 1.0;
+    const double f0 = floor((double)a0), f1 = floor((double)a1);
+    c0 = (uint32_t)(f0 < 0.0 ? 0.0 : (f0 > hi ? hi : f0));   // NaN never reaches here: non-finite spheres are "large"
+    c1 = (uint32_t)(f1 < 0.0 ? 0.0 : (f1 > hi ? hi : f1));
+}
+// classification key of a radius: non-finite radii sort last, so that the median (and with it the small / large split) is
+// defined for every scene and the same on host and device
+APT_HD float grid_radius(float r2) {
+    const float rad = sqrtf(r2 > 0.0f ? r2 : 0.0f);
+    return (rad == rad && rad <= 3.0e38f) ? rad : __builtin_inff();
+}
+APT_HD bool grid_is_large(float r2, float cx, float cy, float cz, float rad, float median) {
+    const bool finite = rad <= 3.0e38f && fabsf(cx) <= 3.0e38f && fabsf(cy) <= 3.0e38f && fabsf(cz) <= 3.0e38f; // false for NaN / inf
+    return !finite || rad > 8.0f * median || !(r2 >= 0.0f);
+}
 
 // ---- Russian roulette (extension, APT_FLAG_RR; specified in include/render_mi355x.h) ------------
 APT_HD uint64_t rr_path_key(uint64_t seed, uint64_t path) { return splitmix64(seed ^ splitmix64(path)); }

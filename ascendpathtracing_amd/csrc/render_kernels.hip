@@ -22,6 +22,7 @@
 #include "pt_core.h"
 
 #include "pt_kernels.h"
+#include "pt_grid_build.h"
 
 namespace {
 
@@ -428,6 +429,76 @@ int apt_multi_render(apt_multi *m, float *fb_root, uint8_t *u8_root, float *band
             if (hipEventElapsedTime(&band_kernel_ms[b], m->bands[b].start, m->bands[b].stop) != hipSuccess) band_kernel_ms[b] = -1.0f;
         }
     (void)hipSetDevice(m->root);
+    if (rc != APT_OK) return rc;
+    return e == hipSuccess ? APT_OK : hip_fail(e);
+}
+
+int apt_build_grid_device(const float *spheres_dev, uint32_t ns, void *stream, void *grid_dev, size_t capacity,
+                          size_t *out_bytes) {
+    clear_error();
+    if (!spheres_dev || ns == 0 || !out_bytes) return fail(APT_ERR_ARG, "apt_build_grid_device: spheres/out_bytes must be non-null, num_spheres non-zero%s");
+    hipStream_t st = (hipStream_t)stream;
+    // workspace: radii, the two ordered lists, statistics (freed on return; a build step, not a render call)
+    float *rad = nullptr;
+    uint32_t *large = nullptr, *small = nullptr, *count = nullptr, *cursor = nullptr, *sums = nullptr;
+    GridBuildStats *stats_d = nullptr;
+    hipError_t e = hipMalloc(&rad, (size_t)ns * 4);
+    if (e == hipSuccess) e = hipMalloc(&large, (size_t)ns * 4);
+    if (e == hipSuccess) e = hipMalloc(&small, (size_t)ns * 4);
+    if (e == hipSuccess) e = hipMalloc(&stats_d, sizeof(GridBuildStats));
+    GridBuildStats stt;
+    int rc = APT_OK;
+    GridHeader h;
+    size_t words = 0;
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(grid_classify_kernel, dim3(1), dim3(kGB), 0, st, spheres_dev, ns, rad, large, small, stats_d);
+        e = hipMemcpyAsync(&stt, stats_d, sizeof stt, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+    }
+    if (e == hipSuccess) {
+        double per_cell = 1.0;
+        if (const char *env = getenv("APT_GRID_SPHERES_PER_CELL")) { const double v = atof(env); if (v > 0.01 && v < 1e6) per_cell = v; }
+        grid_header_from_stats(ns, stt.nsmall, stt.nlarge, stt.lo, stt.hi, stt.scale, per_cell, h);
+        const uint64_t nc1 = (uint64_t)h.ncells + 1, nblk = (nc1 + kGB - 1) / kGB;
+        e = hipMalloc(&count, nc1 * 4);
+        if (e == hipSuccess) e = hipMalloc(&cursor, (size_t)h.ncells * 4);
+        if (e == hipSuccess) e = hipMalloc(&sums, nblk * 4);
+        if (e == hipSuccess) e = hipMemsetAsync(count, 0, nc1 * 4, st);
+        if (e == hipSuccess) e = hipMemsetAsync(cursor, 0, (size_t)h.ncells * 4, st);
+        uint32_t nitems = 0;
+        if (e == hipSuccess) {
+            if (stt.nsmall) hipLaunchKernelGGL(grid_count_kernel, dim3((stt.nsmall + 255) / 256), dim3(256), 0, st, h, spheres_dev, rad, small, stt.nsmall, count);
+            hipLaunchKernelGGL(scan_blocks_kernel, dim3((unsigned)nblk), dim3(kGB), 0, st, count, nc1, sums);
+            hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(kGB), 0, st, sums, (uint32_t)nblk);
+            hipLaunchKernelGGL(scan_add_kernel, dim3((unsigned)nblk), dim3(kGB), 0, st, count, nc1, sums);
+            e = hipMemcpyAsync(&nitems, count + h.ncells, 4, hipMemcpyDeviceToHost, st);
+            if (e == hipSuccess) e = hipStreamSynchronize(st);
+        }
+        if (e == hipSuccess) {
+            words = grid_header_offsets(h, nitems);
+            *out_bytes = words * 4;
+            if (!grid_dev) rc = APT_OK;                                       // size query
+            else if (capacity < words * 4) rc = fail(APT_ERR_ARG, "apt_build_grid_device: capacity too small (see *out_bytes)%s");
+            else {
+                uint32_t *w = (uint32_t *)grid_dev;
+                e = hipMemsetAsync(w, 0, words * 4, st);
+                if (e == hipSuccess) e = hipMemcpyAsync(w, &h, sizeof h, hipMemcpyHostToDevice, st);
+                if (e == hipSuccess && h.nlarge) e = hipMemcpyAsync(w + h.off_large, large, (size_t)h.nlarge * 4, hipMemcpyDeviceToDevice, st);
+                if (e == hipSuccess) e = hipMemcpyAsync(w + h.off_cells, count, nc1 * 4, hipMemcpyDeviceToDevice, st);
+                if (e == hipSuccess) {
+                    if (stt.nsmall) hipLaunchKernelGGL(grid_fill_kernel, dim3((stt.nsmall + 255) / 256), dim3(256), 0, st, h, spheres_dev, rad, small, stt.nsmall, count, cursor, w + h.off_items);
+                    hipLaunchKernelGGL(grid_sort_cells_kernel, dim3((h.ncells + 255) / 256), dim3(256), 0, st, h.ncells, count, w + h.off_items);
+                    const uint32_t ng = ns > nitems ? ns : nitems;
+                    hipLaunchKernelGGL(grid_geom_kernel, dim3((ng + 255) / 256), dim3(256), 0, st, spheres_dev, ns, w + h.off_items, nitems,
+                                       reinterpret_cast<float4 *>(w + h.off_geom), reinterpret_cast<float4 *>(w + h.off_item_geom));
+                    e = hipGetLastError();
+                    if (e == hipSuccess) e = hipStreamSynchronize(st);       // the workspace is freed below
+                }
+            }
+        }
+    }
+    (void)hipFree(rad); (void)hipFree(large); (void)hipFree(small); (void)hipFree(stats_d);
+    (void)hipFree(count); (void)hipFree(cursor); (void)hipFree(sums);
     if (rc != APT_OK) return rc;
     return e == hipSuccess ? APT_OK : hip_fail(e);
 }

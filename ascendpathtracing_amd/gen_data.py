@@ -111,6 +111,24 @@ def build_grid(spheres, num_spheres):
     return buf
 
 
+def build_grid_device(spheres_dev, num_spheres, stream=None):
+    """The same grid built on the GPU from the device-resident table (apt_build_grid_device) -> torch int32 tensor on the
+    device (pass its data_ptr() as RenderParams.accel).  Byte-identical to build_grid()."""
+    import torch
+    from . import render
+    from ._lib import require_gpu
+    require_gpu()
+    st = render._stream_handle(stream)
+    nbytes = ctypes.c_size_t(0)
+    check(lib().apt_build_grid_device(ctypes.c_void_p(spheres_dev.data_ptr()), ctypes.c_uint32(num_spheres), st, None,
+                                      ctypes.c_size_t(0), ctypes.byref(nbytes)), "apt_build_grid_device")
+    buf = torch.empty(nbytes.value // 4, dtype=torch.int32, device=spheres_dev.device)
+    check(lib().apt_build_grid_device(ctypes.c_void_p(spheres_dev.data_ptr()), ctypes.c_uint32(num_spheres), st,
+                                      ctypes.c_void_p(buf.data_ptr()), ctypes.c_size_t(nbytes.value), ctypes.byref(nbytes)),
+          "apt_build_grid_device")
+    return buf
+
+
 if __name__ == "__main__":              # gen_data.py:435-446
     os.makedirs("input", exist_ok=True)
     gen_rays(width, height, samples, seed=0, out_dir="./input")

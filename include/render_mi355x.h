@@ -270,6 +270,14 @@ int apt_gen_scene_host(uint32_t num_spheres, uint64_t seed, float *spheres,
  * the lowest sphere index. */
 int apt_build_grid_host(const float *spheres_host, uint32_t num_spheres, void *grid, size_t *out_bytes);
 
+/* The same grid built ON THE DEVICE from the [10][Ns] table in device memory: byte-identical to what
+ * apt_build_grid_host writes for that scene (radix-select median, scans and atomics in kernels; the scalar header
+ * arithmetic is the host's own).  grid_dev = DEVICE buffer of `capacity` bytes, or NULL to query the size
+ * (*out_bytes).  Synchronous on `stream` (two small read-backs size the buffer) and allocates its workspace: a
+ * build step, not capture-safe.  Up to 512 cells per axis (round 1: 128). */
+int apt_build_grid_device(const float *spheres_dev, uint32_t num_spheres, void *stream, void *grid_dev,
+                          size_t capacity, size_t *out_bytes);
+
 /* P3 writer of scripts/data_visualization.py:11-17 from a [pixel][3] uint8 image in
  * x-major pixel order (q = i*H + j, y not flipped). */
 int apt_write_ppm(const char *path, uint32_t width, uint32_t height, const uint8_t *fb_u8);

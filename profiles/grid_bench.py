@@ -22,6 +22,13 @@ scene = torch.from_numpy(scene_h).cuda()
 t0 = time.time()
 grid = torch.from_numpy(gen_data.build_grid(scene_h, args.ns).view("int32")).cuda()
 t_grid = time.time() - t0
+t0 = time.time()
+dgrid = gen_data.build_grid_device(scene, args.ns); torch.cuda.synchronize()
+t_first = time.time() - t0
+t0 = time.time()
+dgrid = gen_data.build_grid_device(scene, args.ns); torch.cuda.synchronize()
+t_dev = time.time() - t0
+assert torch.equal(dgrid, grid)
 p = apt.make_params(1920, 1080, args.s, depth=args.depth, num_spheres=args.ns, accel=grid.data_ptr(),
                     flags=apt.APT_FLAG_RETIRE if args.retire else 0)
 fb, u8 = render.render_frame(p, scene)
@@ -34,7 +41,8 @@ for _ in range(args.reps):
 seg = p.num_paths * args.depth
 out = {"ns": args.ns, "S": args.s, "depth": args.depth, "ms": round(best, 3), "nominal_gray_per_s": round(seg / best / 1e6, 2),
        "sha256_u8": hashlib.sha256(u8.cpu().numpy().tobytes()).hexdigest()[:16],
-       "grid_build_host_s": round(t_grid, 3), "grid_bytes": int(grid.numel() * 4)}
+       "grid_build_host_s": round(t_grid, 4), "grid_build_device_s": round(t_dev, 4), "grid_build_device_first_call_s": round(t_first, 4),
+       "grid_bytes": int(grid.numel() * 4)}
 if args.stats:
     with render.TraceCounter() as tc:
         render.render_frame(p, scene)
