@@ -550,23 +550,6 @@ __device__ __forceinline__ void grid_stats(const TraceArgs &ta, uint32_t n_cells
     }
 }
 
-// intersect_pre (pt_core.h) for one sphere with the x and y components in one packed instruction each: the same
-// operations in the same order (b = (ocx*dx + ocy*dy) + ocz*dz, c = ((ocx^2 + ocy^2) + ocz^2) - r2), 13 instead of 16
-// instructions -- in the grid walk the candidate tests are most of the work.
-__device__ __forceinline__ HitPre intersect_pre_xy(const float4 g, const f2 oxy, float oz, const f2 dxy, float dz) {
-    const f2 ocxy = f2{g.x, g.y} - oxy;
-    const float ocz = g.z - oz;
-    const f2 pb = ocxy * dxy, pc = ocxy * ocxy;
-    float b = pb.x + pb.y;
-    b = b + ocz * dz;
-    float c = pc.x + pc.y;
-    c = c + ocz * ocz;
-    c = c - g.w;
-    float disc = b * b;
-    disc = disc - c;
-    return {b, disc};
-}
-
 struct GridCtx { // what one segment through the grid needs besides the path (wave-uniform)
     const GridHeader *h;
     const float *sph;
@@ -596,7 +579,7 @@ __device__ __forceinline__ void grid_segment(const GridCtx &ctx, PathState &s, b
         float tmin = kMissT;
     int idx = (MODE == kModeOracle) ? -1 : 0;
     auto test_geom = [&](const float4 g, uint32_t k) {
-        const HitPre hp = intersect_pre_xy(g, s.oxy, s.oz, s.dxy, s.dz);
+        const HitPre hp = intersect_pre(g.x, g.y, g.z, g.w, s.oxy.x, s.oxy.y, s.oz, s.dxy.x, s.dxy.y, s.dz);
         if (hp.disc >= 0.0f) {
             const float t = intersect_post(hp, ta.eps);
             if (t < tmin || (t == tmin && (int)k < idx)) { tmin = t; idx = (int)k; }
@@ -608,7 +591,7 @@ __device__ __forceinline__ void grid_segment(const GridCtx &ctx, PathState &s, b
     // sphere met again in the next cell -- and once at the end for the winner.
     uint32_t pos = ~0u; // item position of the running minimum, ~0u while `idx` itself is authoritative
     auto test_item = [&](const float4 g, uint32_t i) {
-        const HitPre hp = intersect_pre_xy(g, s.oxy, s.oz, s.dxy, s.dz);
+        const HitPre hp = intersect_pre(g.x, g.y, g.z, g.w, s.oxy.x, s.oxy.y, s.oz, s.dxy.x, s.dxy.y, s.dz);
         if (hp.disc >= 0.0f) {
             const float t = intersect_post(hp, ta.eps);
             if (t < tmin) { tmin = t; pos = i; }
@@ -624,7 +607,7 @@ __device__ __forceinline__ void grid_segment(const GridCtx &ctx, PathState &s, b
     // instead of +inf, and neither can beat tmin <= kMissT.
     auto test_large = [&](const float4 g, uint32_t k) {
         ++n_tests;
-        const HitPre hp = intersect_pre_xy(g, s.oxy, s.oz, s.dxy, s.dz);
+        const HitPre hp = intersect_pre(g.x, g.y, g.z, g.w, s.oxy.x, s.oxy.y, s.oz, s.dxy.x, s.dxy.y, s.dz);
         float q;
 #if defined(__HIP_DEVICE_COMPILE__) // the sqrt variants are device-only builtins
         float am = 1.0f;
