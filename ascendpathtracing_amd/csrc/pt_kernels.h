@@ -217,74 +217,130 @@ __global__ __launch_bounds__(kBlock, TWO ? APT_TWO_WAVES : (RETIRE && SC == kSce
                 uint32_t n_bounce_exec = 0, n_gen_exec = 0; // wave-level executions (statistics only)
                 float sl_ox = 0.f, sl_oy = 0.f, sl_oz = 0.f, sl_dx = 0.f, sl_dy = 0.f, sl_dz = 1.f; // the one-ray slot
                 bool slot_full = false, slot_valid = false, cur_valid = false;
-                PathState s;
+                // The loop is written as refill / bounce / refill / bounce with the two bounces exchanging the roles of
+                // the state registers (no copies), the throughput and the alive mask outside that pair (updated in place),
+                // and WITHOUT a merge of the fast and the exact form of a bounce: when a lane whose path can still reach an
+                // output leaves the validity range of the fast sequences, the wave finishes this leaf in the exact loop
+                // below (same queue logic around bounce_ns8<MODE, false>; about 1e-5 of the wave-bounces).
+                PathState s, n;
                 path_init(s, 0.f, 0.f, 0.f, 0.f, 0.f, 1.f);
-                for (;;) {
-                    const bool want = !slot_full;
-                    const unsigned long long wants = __ballot(want);
-                    const bool busy_any = __any(depth_left != 0 || slot_full);
-                    if (next < total && wants && ((uint32_t)__popcll(wants) >= ta.refill_lanes || !busy_any)) {
-                        ++n_gen_exec;
-                        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(wants >> 32),
-                                              __builtin_amdgcn_mbcnt_lo((uint32_t)wants, 0u));
-                        const uint32_t remaining = total - next;
-                        const bool take = want && rank < remaining;
-                        // group coordinates come from the first lane of the item's group; every lane
-                        // of the wave takes part in the shuffles (a masked-off source lane would
-                        // return garbage), lanes that do not take an item use item 0
-                        const uint32_t item = take ? next + rank : 0u;
-                        const uint32_t g = item / nfull, k = item - g * nfull;
-                        const int src = (int)(8u * g);
-                        const uint32_t gpi = __shfl(pi, src, 64), gpj = __shfl(pj, src, 64);
-                        const uint32_t gsub = __shfl(sub, src, 64);
-                        const uint32_t blo = __shfl((uint32_t)pbase, src, 64), bhi = __shfl((uint32_t)(pbase >> 32), src, 64);
-                        const bool gvalid = __shfl((int)valid, src, 64) != 0;
-                        if (take) {
-                            slot_valid = gvalid;
-                            double u1, u2;
-                            const uint64_t path = (((uint64_t)bhi << 32) | blo) + start + k;
-                            if (ta.rr_start) slot_key = rr_path_key(ta.seed, path);
-                            path_uniforms(fa.seed, path, u1, u2);
-                            camera_ray(cam, fa.width, fa.height, gpi, gpj, gsub >> 1, gsub & 1u, u1, u2, sl_ox, sl_oy, sl_oz, sl_dx,
-                                       sl_dy, sl_dz);
-                            slot_item = item;
-                            slot_full = true;
+                n = s;
+                f2 thr_xy = {1.0f, 1.0f};                 // throughput of the lane's running path
+                float thr_z = 1.0f;
+                uint64_t alive = 0;                       // wave mask: running path has not hit the light
+                // Take unissued samples into the one-ray slots (wave-wide float64 ray-generate when enough lanes want one),
+                // start waiting rays in `cur`; -> true when the wave has nothing left to do in this leaf.
+                auto refill = [&](PathState &cur) -> bool {
+                    for (;;) {
+                        const bool want = !slot_full;
+                        const unsigned long long wants = __ballot(want);
+                        const bool busy_any = __any(depth_left != 0 || slot_full);
+                        if (next < total && wants && ((uint32_t)__popcll(wants) >= ta.refill_lanes || !busy_any)) {
+                            ++n_gen_exec;
+                            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(wants >> 32),
+                                                  __builtin_amdgcn_mbcnt_lo((uint32_t)wants, 0u));
+                            const uint32_t remaining = total - next;
+                            const bool take = want && rank < remaining;
+                            // group coordinates come from the first lane of the item's group; every lane
+                            // of the wave takes part in the shuffles (a masked-off source lane would
+                            // return garbage), lanes that do not take an item use item 0
+                            const uint32_t item = take ? next + rank : 0u;
+                            const uint32_t g = item / nfull, k = item - g * nfull;
+                            const int src = (int)(8u * g);
+                            const uint32_t gpi = __shfl(pi, src, 64), gpj = __shfl(pj, src, 64);
+                            const uint32_t gsub = __shfl(sub, src, 64);
+                            const uint32_t blo = __shfl((uint32_t)pbase, src, 64), bhi = __shfl((uint32_t)(pbase >> 32), src, 64);
+                            const bool gvalid = __shfl((int)valid, src, 64) != 0;
+                            if (take) {
+                                slot_valid = gvalid;
+                                double u1, u2;
+                                const uint64_t path = (((uint64_t)bhi << 32) | blo) + start + k;
+                                if (ta.rr_start) slot_key = rr_path_key(ta.seed, path);
+                                path_uniforms(fa.seed, path, u1, u2);
+                                camera_ray(cam, fa.width, fa.height, gpi, gpj, gsub >> 1, gsub & 1u, u1, u2, sl_ox, sl_oy, sl_oz, sl_dx,
+                                           sl_dy, sl_dz);
+                                slot_item = item;
+                                slot_full = true;
+                            }
+                            next += min((uint32_t)__popcll(wants), remaining);
                         }
-                        next += min((uint32_t)__popcll(wants), remaining);
-                    }
-                    if (depth_left == 0 && slot_full) { // start the waiting ray
-                        path_init(s, sl_ox, sl_oy, sl_oz, sl_dx, sl_dy, sl_dz);
-                        cur_item = slot_item;
-                        cur_key = slot_key;
-                        cur_valid = slot_valid;
-                        depth_left = ta.depth;
-                        slot_full = false;
-                        if (ta.depth == 0 || !cur_valid) { // depth 0, or a group past the image: colour = gain
-                            depth_left = 0;
-                            colq[cur_item] = gain.r; colq[qstride + cur_item] = gain.g; colq[2 * qstride + cur_item] = gain.b;
+                        const bool begin = depth_left == 0 && slot_full; // start the waiting ray
+                        if (begin) {
+                            cur.oxy = f2{sl_ox, sl_oy}; cur.oz = sl_oz; cur.dxy = f2{sl_dx, sl_dy}; cur.dz = sl_dz;
+                            thr_xy = f2{1.0f, 1.0f}; thr_z = 1.0f;
+                            cur_item = slot_item;
+                            cur_key = slot_key;
+                            cur_valid = slot_valid;
+                            depth_left = ta.depth;
+                            slot_full = false;
+                            if (ta.depth == 0 || !cur_valid) { // depth 0, or a group past the image: colour = gain
+                                depth_left = 0;
+                                colq[cur_item] = gain.r; colq[qstride + cur_item] = gain.g; colq[2 * qstride + cur_item] = gain.b;
+                            }
                         }
+                        alive |= __builtin_amdgcn_ballot_w64(begin);
+                        if (__any(depth_left != 0)) return false;
+                        if (next >= total && !__any(slot_full)) return true;
                     }
-                    const bool active = depth_left != 0;
-                    if (!__any(active)) {
-                        if (next >= total && !__any(slot_full)) break;
-                        continue;
-                    }
+                };
+                // bookkeeping after a bounce that stands: roulette, counters, finished paths park their colour
+                auto post = [&](bool active) {
                     ++n_bounce_exec;
-                    PathState nx;
-                    uint64_t alive_m = __builtin_amdgcn_ballot_w64(s.alive != 0);
-                    bounce_ns8_checked<MODE>(sc, tab8, s, nx, ta, kc, fast_ok, alive_m, true, __builtin_amdgcn_ballot_w64(active));
-                    if (ta.rr_start && ta.depth - depth_left + 1 >= ta.rr_start) // 0-based bounce index = depth - depth_left
-                        russian_roulette(nx, cur_key, ta.depth - depth_left);
-                    // inactive lanes computed on stale state; whatever they hold is overwritten when
-                    // they start their next ray, so the update itself needs no mask
-                    s = nx;
+                    if (ta.rr_start && ta.depth - depth_left + 1 >= ta.rr_start) { // 0-based bounce index = depth - depth_left
+                        PathState t;
+                        t.rxy = thr_xy; t.rz = thr_z; t.alive = select_const(alive, 1);
+                        russian_roulette(t, cur_key, ta.depth - depth_left);
+                        thr_xy = t.rxy; thr_z = t.rz;
+                    }
                     queue_traced += (active && cur_valid) ? 1u : 0u; // the item's pixel decides, not this lane's own
                     depth_left -= active ? 1u : 0u;
-                    if (active && (depth_left == 0 || path_finished(s))) {
+                    const bool fin = select_const(alive, 1) == 0 || (thr_xy.x == 0.0f && thr_xy.y == 0.0f && thr_z == 0.0f);
+                    if (active && (depth_left == 0 || fin)) {
                         depth_left = 0;
-                        colq[cur_item] = s.rxy.x * gain.r;
-                        colq[qstride + cur_item] = s.rxy.y * gain.g;
-                        colq[2 * qstride + cur_item] = s.rz * gain.b;
+                        colq[cur_item] = thr_xy.x * gain.r;
+                        colq[qstride + cur_item] = thr_xy.y * gain.g;
+                        colq[2 * qstride + cur_item] = thr_z * gain.b;
+                    }
+                };
+                // one fast bounce cur -> nxt (inactive lanes compute on stale state; whatever they hold is overwritten when
+                // they start their next ray); true: the wave must go exact from `cur`, nothing was committed
+                auto step_fast = [&](const PathState &cur, PathState &nxt) -> bool {
+                    const bool active = depth_left != 0;
+                    Albedo albedo;
+                    uint64_t alive_out = alive;
+                    const uint64_t redo = bounce_ns8_v2<MODE>(sc, tab8, cur, nxt, ta, kc, alive_out, albedo) & __builtin_amdgcn_ballot_w64(active);
+                    if (__builtin_expect(redo != 0, 0)) { // a finished path's request is ignored, see trace_ns8
+                        const bool fin = select_const(alive, 1) == 0 || (thr_xy.x == 0.0f && thr_xy.y == 0.0f && thr_z == 0.0f);
+                        if (__any(select_const(redo, 1) != 0 && !fin)) return true;
+                    }
+                    apply_albedo(thr_xy, thr_z, albedo, alive_out);
+                    alive = alive_out;
+                    post(active);
+                    return false;
+                };
+                auto step_exact = [&](PathState &cur, PathState &nxt) {
+                    const bool active = depth_left != 0;
+                    cur.rxy = thr_xy; cur.rz = thr_z; cur.alive = select_const(alive, 1);
+                    (void)bounce_ns8<MODE, false>(sc, tab8, cur, nxt, ta);
+                    thr_xy = nxt.rxy; thr_z = nxt.rz;
+                    alive = __builtin_amdgcn_ballot_w64(nxt.alive != 0);
+                    post(active);
+                };
+                bool done = refill(s), exact = !fast_ok;
+                if (!done && !exact) {
+                    for (;;) {
+                        if (__builtin_expect(step_fast(s, n), 0)) { exact = true; break; }
+                        if ((done = refill(n))) break;
+                        if (__builtin_expect(step_fast(n, s), 0)) { exact = true; s = n; break; }
+                        if ((done = refill(s))) break;
+                    }
+                }
+                if (!done && exact) {
+                    if (ta.traced && lane == 0) atomicAdd(ta.traced + 3, 1ull); // statistics: waves that left the fast loop
+                    for (;;) {
+                        step_exact(s, n);
+                        s = n;
+                        if (refill(s)) break;
                     }
                 }
                 __syncthreads(); // colours of the whole leaf are in LDS (only wave-local data is read back)
