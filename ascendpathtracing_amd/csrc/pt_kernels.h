@@ -54,47 +54,97 @@ __global__ __launch_bounds__(kBlock) void render_paths_queue_kernel(const float 
     const Tab8 tab8 = load_scene8(sph, sc, tab);
     const Gain3 gain = load_gain(sph, ta);
     const KeyConsts kc = make_key_consts(ta.eps);
-    const bool fast_ok = eps_allows_rootkey(ta.eps);
-    const uint64_t wave = (uint64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    // readfirstlane: the wave index is uniform, and the compiler has to know it (the queue's masks live in SGPRs)
+    const uint64_t wave = (uint64_t)blockIdx.x * (kBlock / 64) + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     uint64_t next = wave * kQueueChunk;                         // wave-uniform
     const uint64_t end = min(count, next + kQueueChunk);
     uint32_t depth_left = 0, traced = 0;
     uint64_t cur = 0, cur_key = 0;
-    PathState s;
+    // Same loop shape as the frame kernel's queue (see there): refill / bounce / refill / bounce with the state registers
+    // exchanging roles, throughput and alive mask updated in place, no merge with the exact form inside the loop.
+    PathState s, n;
     path_init(s, 0.f, 0.f, 0.f, 0.f, 0.f, 1.f);
-    for (;;) {
-        const bool want = depth_left == 0;
-        const unsigned long long wants = __ballot(want);
-        if (next < end && wants) {
-            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(wants >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)wants, 0u));
-            const uint64_t remaining = end - next;
-            if (want && rank < remaining) {
-                cur = begin + next + rank;
-                path_init(s, rays[cur], rays[n_total + cur], rays[2 * n_total + cur], rays[3 * n_total + cur],
-                          rays[4 * n_total + cur], rays[5 * n_total + cur]);
-                depth_left = ta.depth;
-                if (ta.rr_start) cur_key = rr_path_key(ta.seed, cur);
-                if (ta.depth == 0) { colors[cur] = gain.r; colors[n_total + cur] = gain.g; colors[2 * n_total + cur] = gain.b; }
+    n = s;
+    f2 thr_xy = {1.0f, 1.0f};
+    float thr_z = 1.0f;
+    uint64_t alive = 0;
+    auto refill = [&](PathState &st) -> bool { // idle lanes take the next unissued paths of the chunk; true: chunk finished
+        for (;;) {
+            const bool want = depth_left == 0;
+            const unsigned long long wants = __ballot(want);
+            if (next < end && wants) {
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(wants >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)wants, 0u));
+                const uint64_t remaining = end - next;
+                const bool take = want && rank < remaining;
+                if (take) {
+                    cur = begin + next + rank;
+                    st.oxy = f2{rays[cur], rays[n_total + cur]}; st.oz = rays[2 * n_total + cur];
+                    st.dxy = f2{rays[3 * n_total + cur], rays[4 * n_total + cur]}; st.dz = rays[5 * n_total + cur];
+                    thr_xy = f2{1.0f, 1.0f}; thr_z = 1.0f;
+                    depth_left = ta.depth;
+                    if (ta.rr_start) cur_key = rr_path_key(ta.seed, cur);
+                    if (ta.depth == 0) { colors[cur] = gain.r; colors[n_total + cur] = gain.g; colors[2 * n_total + cur] = gain.b; }
+                }
+                alive |= __builtin_amdgcn_ballot_w64(take);
+                next += min((uint64_t)__popcll(wants), remaining);
             }
-            next += min((uint64_t)__popcll(wants), remaining);
+            if (__any(depth_left != 0)) return false;
+            if (next >= end) return true;
         }
-        const bool active = depth_left != 0;
-        if (!__any(active)) {
-            if (next >= end) break;
-            continue;
+    };
+    auto post = [&](bool active) {
+        if (ta.rr_start && ta.depth - depth_left + 1 >= ta.rr_start) {
+            PathState t;
+            t.rxy = thr_xy; t.rz = thr_z; t.alive = select_const(alive, 1);
+            russian_roulette(t, cur_key, ta.depth - depth_left);
+            thr_xy = t.rxy; thr_z = t.rz;
         }
-        PathState nx;
-        uint64_t alive_m = __builtin_amdgcn_ballot_w64(s.alive != 0);
-        bounce_ns8_checked<MODE>(sc, tab8, s, nx, ta, kc, fast_ok, alive_m, true, __builtin_amdgcn_ballot_w64(active));
-        if (ta.rr_start && ta.depth - depth_left + 1 >= ta.rr_start) russian_roulette(nx, cur_key, ta.depth - depth_left);
-        s = nx;
         traced += active ? 1u : 0u;
         depth_left -= active ? 1u : 0u;
-        if (active && (depth_left == 0 || path_finished(s))) {
+        const bool fin = select_const(alive, 1) == 0 || (thr_xy.x == 0.0f && thr_xy.y == 0.0f && thr_z == 0.0f);
+        if (active && (depth_left == 0 || fin)) {
             depth_left = 0;
-            colors[cur] = s.rxy.x * gain.r;
-            colors[n_total + cur] = s.rxy.y * gain.g;
-            colors[2 * n_total + cur] = s.rz * gain.b;
+            colors[cur] = thr_xy.x * gain.r;
+            colors[n_total + cur] = thr_xy.y * gain.g;
+            colors[2 * n_total + cur] = thr_z * gain.b;
+        }
+    };
+    auto step_fast = [&](const PathState &in, PathState &out) -> bool { // true: go exact from `in`, nothing committed
+        const bool active = depth_left != 0;
+        Albedo albedo;
+        uint64_t alive_out = alive;
+        const uint64_t redo = bounce_ns8_v2<MODE>(sc, tab8, in, out, ta, kc, alive_out, albedo) & __builtin_amdgcn_ballot_w64(active);
+        if (__builtin_expect(redo != 0, 0)) {
+            const bool fin = select_const(alive, 1) == 0 || (thr_xy.x == 0.0f && thr_xy.y == 0.0f && thr_z == 0.0f);
+            if (__any(select_const(redo, 1) != 0 && !fin)) return true;
+        }
+        apply_albedo(thr_xy, thr_z, albedo, alive_out);
+        alive = alive_out;
+        post(active);
+        return false;
+    };
+    auto step_exact = [&](PathState &in, PathState &out) {
+        const bool active = depth_left != 0;
+        in.rxy = thr_xy; in.rz = thr_z; in.alive = select_const(alive, 1);
+        (void)bounce_ns8<MODE, false>(sc, tab8, in, out, ta);
+        thr_xy = out.rxy; thr_z = out.rz;
+        alive = __builtin_amdgcn_ballot_w64(out.alive != 0);
+        post(active);
+    };
+    bool done = refill(s), exact = !eps_allows_rootkey(ta.eps);
+    if (!done && !exact) {
+        for (;;) {
+            if (__builtin_expect(step_fast(s, n), 0)) { exact = true; break; }
+            if ((done = refill(n))) break;
+            if (__builtin_expect(step_fast(n, s), 0)) { exact = true; s = n; break; }
+            if ((done = refill(s))) break;
+        }
+    }
+    if (!done && exact) {
+        for (;;) {
+            step_exact(s, n);
+            s = n;
+            if (refill(s)) break;
         }
     }
     count_traced(ta, traced);

@@ -189,6 +189,7 @@ __device__ __forceinline__ uint32_t min3_u32(uint32_t a, uint32_t b, uint32_t c)
 }
 __device__ __forceinline__ uint32_t select_const(uint64_t mask, uint32_t value_if_set) { // value must be an inline constant
     uint32_t r;
+    asm("" : "+s"(mask)); // a mask the compiler knows to be constant must still arrive in an SGPR pair
     asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(r) : "n"(value_if_set), "s"(mask));
     return r;
 }
@@ -201,6 +202,7 @@ struct Albedo { f2 xy; float z; };
 // restore pair on the scalar unit) instead of through three selects; other lanes keep their value (x1 is exact).
 __device__ __forceinline__ void apply_albedo(f2 &rxy, float &rz, const Albedo &a, uint64_t alive) {
     uint64_t saved;
+    asm("" : "+s"(alive)); // see select_const
     asm volatile("s_and_saveexec_b64 %[sv], %[m]\n\t"
                  "v_pk_mul_f32 %[rxy], %[cxy], %[rxy]\n\t"
                  "v_mul_f32 %[rz], %[cz], %[rz]\n\t"
