@@ -97,18 +97,21 @@ def gen_rays(w, h, s, seed=0):
     return rays.reshape(6, n)
 
 
-def gen_rays_window(w, h, s, first_block, first_path, count, seed=0, state_in=None):
+def gen_rays_window(w, h, s, first_block, first_path, count, seed=0, state_in=None, want_end=False):
     """MT19937 gen_rays for paths [first_path, first_path+count) -> (rays [6][count] band-relative, raw state of block
-    first_block uint32[624]).  state_in: that raw state (skips the walk from the seed)."""
+    first_block uint32[624]) (+ the raw state of block (first_path+count)//156 when want_end: windows chain).
+    state_in: the raw state of first_block (skips the walk from the seed)."""
     rays = np.zeros(6 * count, dtype=np.float32)
     st_out = np.zeros(624, dtype=np.uint32)
+    st_end = np.zeros(624, dtype=np.uint32)
     st_in = None if state_in is None else np.ascontiguousarray(state_in, dtype=np.uint32)
     rc = lib().oracle_gen_rays_window(ctypes.c_uint32(w), ctypes.c_uint32(h), ctypes.c_uint32(s), ctypes.c_uint32(seed),
                                       None if st_in is None else _ptr(st_in, ctypes.c_uint32), ctypes.c_uint64(first_block),
-                                      ctypes.c_uint64(first_path), ctypes.c_uint64(count), _ptr(rays), _ptr(st_out, ctypes.c_uint32))
+                                      ctypes.c_uint64(first_path), ctypes.c_uint64(count), _ptr(rays), _ptr(st_out, ctypes.c_uint32),
+                                      _ptr(st_end, ctypes.c_uint32) if want_end else None)
     if rc:
         raise ValueError("oracle_gen_rays_window: first_path lies before the window")
-    return rays.reshape(6, count), st_out
+    return (rays.reshape(6, count), st_out, st_end) if want_end else (rays.reshape(6, count), st_out)
 
 
 def gen_rays_counter(params):

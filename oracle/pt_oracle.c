@@ -333,9 +333,11 @@ int oracle_gen_rays(uint32_t w, uint32_t h, uint32_t s, uint32_t seed, float *ra
  * state_in = the raw 624-word generator state whose tempering is output block first_block (624 words = the 4 words
  * of paths [156*first_block, 156*first_block+156)), or NULL to walk there from the seed.  Writes band-relative planes
  * rays[k*count + (p - first_path)] for paths [first_path, first_path+count), first_path >= 156*first_block.
- * state_out (or NULL): the raw state of block first_block (what a later call can pass as state_in). */
+ * state_out (or NULL): the raw state of block first_block (what a later call can pass as state_in).
+ * state_end (or NULL): the raw state of block (first_path+count)/156, i.e. what the window that continues at path
+ * first_path+count passes as state_in with that block as its first_block (windows chain without walking from the seed). */
 int oracle_gen_rays_window(uint32_t w, uint32_t h, uint32_t s, uint32_t seed, const uint32_t *state_in, uint64_t first_block,
-                           uint64_t first_path, uint64_t count, float *rays, uint32_t *state_out) {
+                           uint64_t first_path, uint64_t count, float *rays, uint32_t *state_out, uint32_t *state_end) {
     mt19937 m;
     if (state_in) { memcpy(m.mt, state_in, sizeof m.mt); m.idx = 0; }
     else {
@@ -356,6 +358,10 @@ int oracle_gen_rays_window(uint32_t w, uint32_t h, uint32_t s, uint32_t seed, co
         float ray[6];
         camera_ray(&c, w, h, i, j, sy, sx, u1, u2, ray);
         for (int k = 0; k < 6; ++k) rays[(uint64_t)k * count + q] = ray[k];
+    }
+    if (state_end) {
+        if (m.idx >= 624) { m.idx = 624; (void)mt_next(&m); } /* exactly at a block boundary: the next block's state is one twist away */
+        memcpy(state_end, m.mt, sizeof m.mt);
     }
     return 0;
 }

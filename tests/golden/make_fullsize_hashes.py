@@ -81,6 +81,8 @@ CASES = {
 # The reference's EXACT pipeline (MT19937 gen_rays -> test_soa arithmetic (O-mode) -> decode_color) on pixel ranges of
 # the big configurations: "mt_state" names the committed generator state the window starts from (None = from the seed).
 MT_CASES = {
+    # the WHOLE C2 frame through the reference's exact pipeline, in 16 chunks whose generator states chain
+    "C2_mt_whole": dict(w=1920, h=1080, s=64, depth=8, ranges=chunks(1920 * 1080, 16), mt_state=None, chain=True),
     "C2_mt_first_band": dict(w=1920, h=1080, s=64, depth=8, ranges=[[0, 8192]], mt_state=None),
     "C3_mt_last_column": dict(w=4096, h=4096, s=256, depth=8, ranges=[[4096 * 4096 - 4096, 4096]], mt_state="mt19937_state_c3.npz"),
 }
@@ -91,6 +93,7 @@ def run_mt_case(name, case, threads):
     sph = oracle.gen_spheres()
     t0 = time.time()
     fb_sha, u8_sha = [], []
+    chained = None
     for b, c in case["ranges"]:
         first_path, count = b * 4 * s, c * 4 * s
         state, blk = None, first_path // 156
@@ -98,7 +101,9 @@ def run_mt_case(name, case, threads):
             f = np.load(os.path.join(ROOT, "tests", "golden", case["mt_state"]))
             assert int(f["block"]) == blk, (int(f["block"]), blk)
             state = f["state"]
-        rays, _ = oracle.gen_rays_window(w, h, s, blk, first_path, count, seed=0, state_in=state)
+        if case.get("chain") and chained is not None:
+            state = chained                                   # raw state of block blk, handed on by the previous chunk
+        rays, _, chained = oracle.gen_rays_window(w, h, s, blk, first_path, count, seed=0, state_in=state, want_end=True)
         # the band as an image of c x 1 pixels: the render does not look at pixel coordinates, decode_color only at the grouping
         p = oracle.make_params(c, 1, s, depth=case["depth"], mode=oracle.MODE_O, flags=oracle.FLAG_RETIRE)
         colors, _ = oracle.render_paths(p, rays, sph, threads=threads)

@@ -175,8 +175,10 @@ def test_exact_reference_pipeline_in_bands_c2_and_c3(apt):
     around 1.7e10, generator state taken from the committed fixture instead of walking 1.1e8 blocks)."""
     import torch
     cases = _mt_cases()
-    assert set(cases) >= {"C2_mt_first_band", "C3_mt_last_column"}
+    assert set(cases) >= {"C2_mt_first_band", "C3_mt_last_column", "C2_mt_whole"}
     for name, case in cases.items():
+        if case.get("chain"):
+            continue                               # the whole-frame case is checked by the banded-vs-unbanded test below
         state = None
         if case["mt_state"]:
             f = np.load(os.path.join(ROOT, "tests", "golden", case["mt_state"]))
@@ -210,3 +212,9 @@ def test_exact_reference_pipeline_whole_c2_banded_equals_unbanded(apt):
     case = _mt_cases()["C2_mt_first_band"]
     b, c = case["ranges"][0]
     assert sha(fb[:, b:b + c].cpu().numpy()) == case["fb_sha256"][0] and sha(u8[b:b + c].cpu().numpy()) == case["u8_sha256"][0]
+    whole = _mt_cases()["C2_mt_whole"]            # all 2 073 600 pixels of the reference's exact pipeline against the oracle
+    fbh, u8h = fb.cpu().numpy(), u8.cpu().numpy()
+    assert sum(c for _, c in whole["ranges"]) == w * h
+    bad = [k for k, (b, c) in enumerate(whole["ranges"])
+           if sha(fbh[:, b:b + c]) != whole["fb_sha256"][k] or sha(u8h[b:b + c]) != whole["u8_sha256"][k]]
+    assert not bad, bad
