@@ -178,6 +178,57 @@ def extras(torch, apt, render, gen_data, cfg, sph, steps):
     return out
 
 
+def dry_run(args):
+    """bench.py's N-rank control flow on CPU with gloo and a no-op in place of the render launch.  Nothing is
+    measured and nothing of the oracle is touched: this only proves that `torchrun ... bench.py --gpus N` rendezvouses,
+    shards C3's geometry (scaled down), gathers asynchronously into rank 0's frame and prints one well-formed line."""
+    import torch
+    import torch.distributed as dist
+    import ascendpathtracing_amd as apt
+    from ascendpathtracing_amd import dist as apt_dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus} (WORLD_SIZE is {world})")
+    if world > 1:
+        dist.init_process_group("gloo")
+    cfg = dict(C3 if world > 1 else C2, w=64, h=64, s=8)          # same code path, toy size
+    W, H, S, D = cfg["w"], cfg["h"], cfg["s"], cfg["depth"]
+    p = apt.make_params(W, H, S, depth=D, num_spheres=NS, seed=0)
+    shard = apt_dist.FrameShard(p, rank, world, device="cpu", slots=2, stripes=args.stripes if world > 1 else 1)
+    slots = shard.alloc_slots()
+    full = shard.alloc_full() if rank == 0 else (None, None)
+
+    def fake_render(params, spheres, pixel_begin, pixel_count, fb=None, fb_u8=None):   # writes the pixel index: the gather is checkable
+        idx = torch.arange(pixel_begin, pixel_begin + pixel_count, dtype=torch.float32)
+        fb.copy_(idx.repeat(3, 1))
+        fb_u8.copy_((idx.to(torch.int64) % 251).to(torch.uint8).repeat(3, 1).t())
+
+    t0 = time.perf_counter()
+    for k in range(args.warmup + args.steps):
+        shard.render(slots[k % 2], None, fake_render)
+        if world > 1:
+            shard.gather_async(k % 2, *full)
+    shard.finish()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    ok = True
+    if rank == 0 and world > 1:
+        want = torch.arange(W * H, dtype=torch.float32)
+        ok = bool(torch.equal(full[0][0], want) and torch.equal(full[1][:, 2], (torch.arange(W * H) % 251).to(torch.uint8)))
+    if rank == 0:
+        print(json.dumps({"metric": "dry run (no render, no measurement)", "dry_run": True, "value": None, "unit": "Mray/s", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "scaling": "strong" if world > 1 else "weak",
+                          "config": {"workload": f"{cfg['name']} geometry at toy size {W}x{H}", "pixels_per_rank": shard.pixel_count,
+                                     "stripes": shard.stripes}, "gathered_frame_complete": ok}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # before anything initialises HIP (dmabuf IPC only on this pool)
     ap = argparse.ArgumentParser()
@@ -188,7 +239,13 @@ def main():
     ap.add_argument("--stripes", type=int, default=1, help="interleaved stripes per rank (N > 1; see dist.py)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="control-flow rehearsal without a GPU (tests/test_bench_dry_run.py): gloo, CPU tensors, a tiny frame and NO "
+                         "render at all (the launch is a no-op) -- exercises the rendezvous, sharding, double-buffered gather, "
+                         "reductions and the JSON line; the numbers mean nothing and the line says so")
     args = ap.parse_args()
+    if args.dry_run:
+        return dry_run(args)
 
     import __graft_entry__
     __graft_entry__.build()                   # incremental, serialised by a file lock; does not touch the GPU

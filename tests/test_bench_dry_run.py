@@ -1,0 +1,44 @@
+"""`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` rehearsed on CPU: bench.py's --dry-run keeps the
+launch / rendezvous / sharding / double-buffered gather / JSON code path and replaces the render by a no-op (no GPU, no
+oracle, nothing measured).  The real multi-GPU run is the driver's; this proves the control flow it will take."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.parametrize("n,extra", [(2, []), (8, []), (3, ["--stripes", "5"])])
+def test_torchrun_bench_dry_run(n, extra):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "3", "--warmup", "1",
+           "--dry-run"] + extra
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=dict(os.environ, OMP_NUM_THREADS="1"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout                      # rank 0 prints ONE line
+    out = json.loads(lines[0])
+    assert out["dry_run"] is True and out["n_gpus"] == n and out["steps"] == 3 and out["warmup"] == 1
+    assert out["scaling"] == "strong" and out["gathered_frame_complete"] is True
+    assert "C3" in out["config"]["workload"]
+
+
+def test_single_process_dry_run_and_world_mismatch():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dry-run", "--steps", "2", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-1000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert out["n_gpus"] == 1 and out["scaling"] == "weak"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dry-run", "--gpus", "4"], capture_output=True, text=True,
+                       timeout=300, cwd=ROOT)
+    assert r.returncode != 0 and "nproc-per-node 4" in (r.stderr + r.stdout)
