@@ -167,7 +167,7 @@ struct FrameArgs {
 // TWO: two samples of a lane's chain are traced at a time (pt_trace2.h); only with SC == kScene8, GROUP == 8, no
 // retirement, no roulette (the host picks the kernel).
 template <int MODE, int SC, int GROUP, bool RETIRE, bool TWO = false>
-__global__ __launch_bounds__(kBlock, TWO ? APT_TWO_WAVES : (RETIRE && SC == kScene8 && GROUP == 8) ? APT_QUEUE_WAVES : (SC == kSceneGrid ? APT_GRID_WAVES : APT_FULL_WAVES)) void render_frame_kernel(const float *__restrict__ sph, FrameArgs fa,
+__global__ __launch_bounds__(kBlock, TWO ? APT_TWO_WAVES : (RETIRE && SC == kScene8 && GROUP == 8) ? APT_QUEUE_WAVES : (SC == kSceneGrid ? APT_GRID_WAVES : (SC == kSceneTiles ? APT_TILE_WAVES : APT_FULL_WAVES))) void render_frame_kernel(const float *__restrict__ sph, FrameArgs fa,
                                                               TraceArgs ta, LeafProg lp) {
     constexpr bool NS8 = SC == kScene8;
     __shared__ float4 tab[kTab8Floats4];
@@ -245,8 +245,9 @@ __global__ __launch_bounds__(kBlock, TWO ? APT_TWO_WAVES : (RETIRE && SC == kSce
             acc[0] = a.r; acc[1] = a.g; acc[2] = a.b;
         } else {          // 8 <= n <= 128: r[j] chains, tree, tail
             const uint32_t nfull = n & ~7u;
-            if (RETIRE && NS8) {
-                // Active-ray compaction with a wave-level work queue.  (The same queue around grid_segment() for large
+            if (RETIRE && (NS8 || SC == kSceneTiles)) {
+                // Active-ray compaction with a wave-level work queue (the 8-sphere scene, and any scene by brute force
+                // over LDS tiles, where a "bounce" is one workgroup-synchronous pass over the scene).  (The same queue around grid_segment() for large
                 // scenes is bit-identical but slower than the plain per-lane walk with wave-level early exit -- C4 256 spp:
                 // 288 / 318 / 371 ms at 6 / 5 / 4 waves per SIMD against 232 ms: the walk is latency bound and the queue's
                 // extra state costs occupancy; measured in round 2, not kept.)  The 8 sub-pixel groups of the
@@ -318,6 +319,7 @@ __global__ __launch_bounds__(kBlock, TWO ? APT_TWO_WAVES : (RETIRE && SC == kSce
                         if (begin) {
                             cur.oxy = f2{sl_ox, sl_oy}; cur.oz = sl_oz; cur.dxy = f2{sl_dx, sl_dy}; cur.dz = sl_dz;
                             thr_xy = f2{1.0f, 1.0f}; thr_z = 1.0f;
+                            if (!NS8) { cur.rxy = f2{1.0f, 1.0f}; cur.rz = 1.0f; cur.alive = 1u; } // the tile form keeps these in the state
                             cur_item = slot_item;
                             cur_key = slot_key;
                             cur_valid = slot_valid;
@@ -376,7 +378,30 @@ __global__ __launch_bounds__(kBlock, TWO ? APT_TWO_WAVES : (RETIRE && SC == kSce
                     alive = __builtin_amdgcn_ballot_w64(nxt.alive != 0);
                     post(active);
                 };
-                bool done = refill(s), exact = !fast_ok;
+                if (!NS8) {
+                    // LDS-tile traversal: the scene pass contains workgroup barriers, so the four waves of the workgroup take
+                    // their passes together and leave together; a wave whose queue is empty keeps staging tiles with all its
+                    // lanes inactive.  Every lane does the same work per segment here, so what the queue buys is exactly the
+                    // dead lane-segments (19 % at depth 8 on the 10 000-sphere scene, most of them with roulette).
+                    for (;;) {
+                        const bool wave_done = refill(s);
+                        if (__syncthreads_and(wave_done)) break;
+                        const bool active = depth_left != 0;
+                        dyn_segment<MODE>(sph, tile, s, !active, ta);
+                        ++n_bounce_exec;
+                        if (active && ta.rr_start && ta.depth - depth_left + 1 >= ta.rr_start)
+                            russian_roulette(s, cur_key, ta.depth - depth_left);
+                        queue_traced += (active && cur_valid) ? 1u : 0u;
+                        depth_left -= active ? 1u : 0u;
+                        if (active && (depth_left == 0 || path_finished(s))) {
+                            depth_left = 0;
+                            colq[cur_item] = s.rxy.x * gain.r;
+                            colq[qstride + cur_item] = s.rxy.y * gain.g;
+                            colq[2 * qstride + cur_item] = s.rz * gain.b;
+                        }
+                    }
+                }
+                bool done = !NS8 || refill(s), exact = !fast_ok;
                 if (!done && !exact) {
                     for (;;) {
                         if (__builtin_expect(step_fast(s, n), 0)) { exact = true; break; }

@@ -23,6 +23,9 @@ constexpr int kMaxLeaves = 64;   // pairwise-sum leaves -> samples <= 8192
 #define APT_GRID_WAVES 8 // min waves per SIMD requested for the grid-walk kernels: the walk is latency bound
                          // (dependent cell -> item loads), measured 464 / 371 / 334 / 311 / 302 ms at 3 / 4 / 5 / 6 / 8 waves
 #endif
+#ifndef APT_TILE_WAVES
+#define APT_TILE_WAVES 6 // min waves per SIMD of the LDS-tile frame kernels (4 / 5 / 6 measured within 1 % of each other on C4 brute force)
+#endif
 #ifndef APT_TWO_WAVES
 #define APT_TWO_WAVES 4 // min waves per SIMD of the two-paths-per-lane frame kernel (pt_trace2.h): twice the path state
 #endif
@@ -471,66 +474,78 @@ __device__ __forceinline__ uint32_t trace_ns8(const Scene8 &sc, const Tab8 tab, 
 
 // ---- trace: any scene, LDS-staged tiles -------------------------------------------------
 // Every thread of the workgroup must call this together (it contains barriers).
+// One segment of every lane of the WORKGROUP against the whole scene (brute force over LDS-staged tiles) followed by the
+// shading step; the state of lanes with `fin` is left alone.  Every thread of the workgroup must call this together
+// (it contains barriers).  Roulette and counters are the caller's.
+template <int MODE>
+__device__ __forceinline__ void dyn_segment(const float *__restrict__ sph, float4 *tile, PathState &s, bool fin,
+                                            const TraceArgs &ta) {
+    const uint32_t ns = ta.ns;
+    const float *r2 = sph, *cx = sph + ns, *cy = sph + 2 * (size_t)ns, *cz = sph + 3 * (size_t)ns;
+    const float *colx = sph + 7 * (size_t)ns, *coly = sph + 8 * (size_t)ns, *colz = sph + 9 * (size_t)ns;
+        float tmin = kMissT;
+    int idx = (MODE == kModeOracle) ? -1 : 0;
+    for (uint32_t base = 0; base < ns; base += kTile) {
+        const uint32_t n = min((uint32_t)kTile, ns - base);
+        __syncthreads(); // previous tile fully consumed
+        {   // stage: coalesced plane loads, pair-interleaved LDS layout, NaN spheres pad the tail to a
+            // multiple of 4 (a NaN discriminant is never >= 0, so a pad can never hit)
+            float *tf = reinterpret_cast<float *>(tile);
+            const uint32_t n4 = (n + 3u) & ~3u;
+            for (uint32_t k = threadIdx.x; k < n4; k += kBlock) {
+                const bool real = k < n;
+                const float qn = __uint_as_float(0x7fc00000u);
+                const uint32_t o = (k >> 1) * 8u + (k & 1u);
+                tf[o] = real ? cx[base + k] : qn;
+                tf[o + 2] = real ? cy[base + k] : qn;
+                tf[o + 4] = real ? cz[base + k] : qn;
+                tf[o + 6] = real ? r2[base + k] : qn;
+            }
+        }
+        __syncthreads();
+        // Four spheres per step: four wave-uniform ds_read_b128 broadcasts in flight together, two
+        // packed discriminant evaluations, ONE test "can any lane hit any of the four?".  A
+        // negative discriminant yields kMissT, which never wins the strict '<', so skipping the
+        // sqrt/root half for misses is result preserving; hits are then taken in ascending
+        // sphere order, which keeps the lowest-index-on-ties rule.
+        auto hit = [&](float b, float disc, uint32_t sphere) {
+            if (__any(disc >= 0.0f)) {
+                const float t = intersect_post(HitPre{b, disc}, ta.eps);
+                if (t < tmin) { tmin = t; idx = (int)sphere; }
+            }
+        };
+        for (uint32_t k = 0; k < n; k += 4) {
+            const float4 a0 = tile[k], c0 = tile[k + 1], a1 = tile[k + 2], c1 = tile[k + 3];
+            const HitPre2 h01 = intersect_pre2(a0, c0, s.oxy.x, s.oxy.y, s.oz, s.dxy.x, s.dxy.y, s.dz);
+            const HitPre2 h23 = intersect_pre2(a1, c1, s.oxy.x, s.oxy.y, s.oz, s.dxy.x, s.dxy.y, s.dz);
+            const float m = fmaxf(fmaxf(h01.disc.x, h01.disc.y), fmaxf(h23.disc.x, h23.disc.y)); // NaNs drop out
+            if (__any(m >= 0.0f)) {
+                hit(h01.b.x, h01.disc.x, base + k);
+                hit(h01.b.y, h01.disc.y, base + k + 1);
+                hit(h23.b.x, h23.disc.x, base + k + 2);
+                hit(h23.b.y, h23.disc.y, base + k + 3);
+            }
+        }
+    }
+    const uint32_t g = (idx < 0) ? ns - 1 : (uint32_t)idx;
+    PathState n = s;
+    shade_and_reflect<MODE>(n, tmin, cx[g], cy[g], cz[g], colx[g], coly[g], colz[g], idx == ta.light);
+    if (!fin) s = n;
+}
+
 template <int MODE, bool RETIRE>
 __device__ __forceinline__ uint32_t trace_dyn(const float *__restrict__ sph, float4 *tile, PathState &s, bool valid,
                                               const TraceArgs &ta, uint64_t path) {
     const uint64_t rr_key = ta.rr_start ? rr_path_key(ta.seed, path) : 0;
-    const uint32_t ns = ta.ns;
-    const float *r2 = sph, *cx = sph + ns, *cy = sph + 2 * (size_t)ns, *cz = sph + 3 * (size_t)ns;
-    const float *colx = sph + 7 * (size_t)ns, *coly = sph + 8 * (size_t)ns, *colz = sph + 9 * (size_t)ns;
     uint32_t traced = 0;
     for (uint32_t d = 0; d < ta.depth; ++d) {
         const bool fin = !valid || (RETIRE && path_finished(s));
         if (RETIRE && __syncthreads_and(fin)) break;
-        float tmin = kMissT;
-        int idx = (MODE == kModeOracle) ? -1 : 0;
-        for (uint32_t base = 0; base < ns; base += kTile) {
-            const uint32_t n = min((uint32_t)kTile, ns - base);
-            __syncthreads(); // previous tile fully consumed
-            {   // stage: coalesced plane loads, pair-interleaved LDS layout, NaN spheres pad the tail to a
-                // multiple of 4 (a NaN discriminant is never >= 0, so a pad can never hit)
-                float *tf = reinterpret_cast<float *>(tile);
-                const uint32_t n4 = (n + 3u) & ~3u;
-                for (uint32_t k = threadIdx.x; k < n4; k += kBlock) {
-                    const bool real = k < n;
-                    const float qn = __uint_as_float(0x7fc00000u);
-                    const uint32_t o = (k >> 1) * 8u + (k & 1u);
-                    tf[o] = real ? cx[base + k] : qn;
-                    tf[o + 2] = real ? cy[base + k] : qn;
-                    tf[o + 4] = real ? cz[base + k] : qn;
-                    tf[o + 6] = real ? r2[base + k] : qn;
-                }
-            }
-            __syncthreads();
-            // Four spheres per step: four wave-uniform ds_read_b128 broadcasts in flight together, two
-            // packed discriminant evaluations, ONE test "can any lane hit any of the four?".  A
-            // negative discriminant yields kMissT, which never wins the strict '<', so skipping the
-            // sqrt/root half for misses is result preserving; hits are then taken in ascending
-            // sphere order, which keeps the lowest-index-on-ties rule.
-            auto hit = [&](float b, float disc, uint32_t sphere) {
-                if (__any(disc >= 0.0f)) {
-                    const float t = intersect_post(HitPre{b, disc}, ta.eps);
-                    if (t < tmin) { tmin = t; idx = (int)sphere; }
-                }
-            };
-            for (uint32_t k = 0; k < n; k += 4) {
-                const float4 a0 = tile[k], c0 = tile[k + 1], a1 = tile[k + 2], c1 = tile[k + 3];
-                const HitPre2 h01 = intersect_pre2(a0, c0, s.oxy.x, s.oxy.y, s.oz, s.dxy.x, s.dxy.y, s.dz);
-                const HitPre2 h23 = intersect_pre2(a1, c1, s.oxy.x, s.oxy.y, s.oz, s.dxy.x, s.dxy.y, s.dz);
-                const float m = fmaxf(fmaxf(h01.disc.x, h01.disc.y), fmaxf(h23.disc.x, h23.disc.y)); // NaNs drop out
-                if (__any(m >= 0.0f)) {
-                    hit(h01.b.x, h01.disc.x, base + k);
-                    hit(h01.b.y, h01.disc.y, base + k + 1);
-                    hit(h23.b.x, h23.disc.x, base + k + 2);
-                    hit(h23.b.y, h23.disc.y, base + k + 3);
-                }
-            }
+        dyn_segment<MODE>(sph, tile, s, fin, ta);
+        if (!fin) {
+            if (ta.rr_start && d + 1 >= ta.rr_start) russian_roulette(s, rr_key, d);
+            ++traced;
         }
-        const uint32_t g = (idx < 0) ? ns - 1 : (uint32_t)idx;
-        PathState n = s;
-        shade_and_reflect<MODE>(n, tmin, cx[g], cy[g], cz[g], colx[g], coly[g], colz[g], idx == ta.light);
-        if (ta.rr_start && d + 1 >= ta.rr_start) russian_roulette(n, rr_key, d);
-        if (!fin) { s = n; ++traced; }
     }
     return traced;
 }

@@ -169,7 +169,7 @@ int do_render_frame(const apt_context::Values &cv, const apt_render_params *p, v
     fa.pixel_begin = pixel_begin; fa.pixel_count = pixel_count; fa.fb = fb; fa.fb_u8 = fb_u8;
     const bool retire = p->flags & APT_FLAG_RETIRE;
     size_t lds = lp.nleaves > 1 ? (size_t)kMaxStack * 3 * kStackSlots * sizeof(float) : 0;
-    if (retire && ns8 && group == 8) lds += (size_t)(kBlock / 64) * 3 * 8 * lp.maxleaf * sizeof(float); // colour queue
+    if (retire && (ns8 || !ta.grid) && group == 8) lds += (size_t)(kBlock / 64) * 3 * 8 * lp.maxleaf * sizeof(float); // colour queue
     const dim3 grid((unsigned)blocks);
     const int sck = ns8 ? kScene8 : (ta.grid ? kSceneGrid : kSceneTiles);
     if (p->mode == APT_MODE_ORACLE) {
