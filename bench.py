@@ -135,6 +135,23 @@ def quality_check(cfg, fb, u8, pixels=2048):
             "reference": "oracle C restatement, K-mode", "target_rms": 1e-4}
 
 
+def gathered_frame_check(full_fb, full_u8, case_name="C3_bands"):
+    """N > 1: the frame rank 0 holds after the gather against the oracle-made hashes committed under tests/golden/
+    (data, made by tests/golden/make_fullsize_hashes.py): first and last image column of each of the reference's 8 bands."""
+    import hashlib
+    import numpy as np
+    with open(os.path.join(ROOT, "tests", "golden", "fullsize_hashes.json")) as f:
+        case = json.load(f)["cases"][case_name]
+    bad = []
+    for k, (b, c) in enumerate(case["ranges"]):
+        fb = np.ascontiguousarray(full_fb[:, b:b + c].cpu().numpy())
+        u8 = np.ascontiguousarray(full_u8[b:b + c].cpu().numpy())
+        if hashlib.sha256(fb.tobytes()).hexdigest() != case["fb_sha256"][k] or hashlib.sha256(u8.tobytes()).hexdigest() != case["u8_sha256"][k]:
+            bad.append(k)
+    return {"checked_against": f"tests/golden/fullsize_hashes.json:{case_name} (oracle, {len(case['ranges'])} column ranges of the gathered frame)",
+            "ranges": len(case["ranges"]), "mismatching_ranges": bad, "ok": not bad}
+
+
 def timed(torch, fn, reps):
     fn(); torch.cuda.synchronize()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
@@ -264,11 +281,16 @@ def main():
                          f"(WORLD_SIZE is {world})")
     apt._lib.require_gpu()
     ndev = torch.cuda.device_count()
+    if os.environ.get("APT_BENCH_SHARE_GPU") == "1" and ndev:   # rehearsal on a one-GPU box only (profiles/run_share_gpu.sh):
+        local_rank %= ndev                                       # ranks share a card, the numbers are no measurement
     if local_rank >= ndev:
         raise SystemExit(f"LOCAL_RANK {local_rank} but only {ndev} GPU(s) visible: one process per GPU, no sharing")
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if os.environ.get("APT_BENCH_SHARE_GPU") == "1":   # RCCL refuses two ranks on one card ("Duplicate GPU detected")
+            dist.init_process_group("gloo")                # gloo stages the CUDA tensors through the host
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     workload = args.workload
     if workload == "auto":
@@ -355,6 +377,8 @@ def main():
                         "slowest_band_kernel_ms": round(max(per_rank_ms), 3),
                         "uncovered_gather_and_sync_ms_per_step": round(ms_per_step - max(per_rank_ms), 3),
                         "load_imbalance_max_over_mean": round(max(per_rank_ms) / (sum(per_rank_ms) / world), 4)}
+    if rank == 0 and world > 1 and workload == "c3":
+        out["quality"] = gathered_frame_check(*full)       # the last frame's gather has finished (sync above)
     if rank == 0 and world == 1:
         if not args.no_cpu_baseline:
             fbv, u8v = slots[(args.steps - 1) % 2][0]
@@ -362,6 +386,9 @@ def main():
             out["cpu_baseline"] = cpu_baseline(cfg)
         if not args.no_extra and workload == "c2":
             out["extra"] = extras(torch, apt, render, gen_data, cfg, sph, max(3, args.steps // 2))
+    if os.environ.get("APT_BENCH_SHARE_GPU") == "1":
+        out["rehearsal"] = "ranks shared one GPU (APT_BENCH_SHARE_GPU=1): control flow and gather only, NOT a measurement"
+        out["value"] = None
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
