@@ -62,6 +62,10 @@ def child(name, path, reps):
     out["c2_retire_ms_min_med"] = timeit(params(8, flags=1))
     out["c2_omode_ms_min_med"] = timeit(params(8, mode=1))
     out["c5_d32_ms_min_med"] = timeit(params(32))
+    out["c5_d32_retire_ms_min_med"] = timeit(params(32, flags=1))
+    out["c5_d32_rr_retire_ms_min_med"] = timeit(params(32, flags=3))
+    out["c5_d32_rr_ms_min_med"] = timeit(params(32, flags=2))      # one path per lane, no queue
+    out["c2_omode_retire_ms_min_med"] = timeit(params(8, flags=1, mode=1))
     print(json.dumps(out), flush=True)
 
 
