@@ -172,13 +172,29 @@ __device__ __forceinline__ bool bounce_ns8(const Scene8 &sc, const Tab8 tab, con
 //     instruction per sphere pair, two in the shading step;
 //   * the throughput update runs under the alive mask (exec) instead of through three selects;
 //   * "does any lane need the exact re-run" is the OR of two wave masks, not a materialised boolean.
-struct KeyConsts { uint32_t bias, init; };
+struct KeyConsts { uint32_t bias, init; uint64_t nbias2; };
 __device__ __forceinline__ KeyConsts make_key_consts(float eps) {
     KeyConsts kc;
     kc.bias = f32_bits(eps) + 1u;
     kc.init = f32_bits(kMissT) - kc.bias;
+    // keys of a (-t0, t1) register pair by ONE 64-bit add (root_pair / intersect_ns8_v2)
+    kc.nbias2 = ((uint64_t)(0u - kc.bias) << 32) | (0x80000000u - kc.bias);
     asm volatile("" : "+v"(kc.bias), "+v"(kc.init)); // opaque: the compiler must keep them in VGPRs
+    asm volatile("" : "+s"(kc.nbias2));
     return kc;
+}
+#ifndef APT_KEY64
+#define APT_KEY64 1
+#endif
+// (-t0, t1) = (q - b, b + q) of ONE sphere as the two halves of a register pair, from the packed (sphere k, sphere k+1)
+// operands: v_pk_add_f32 with both result halves reading half `HALF` of the sources and the low half negating b
+// (exact: round-to-nearest is symmetric, q - b is -(b - q) bit for bit).
+template <int HALF>
+__device__ __forceinline__ uint64_t root_pair(f2 b, f2 q) {
+    uint64_t r;
+    if (HALF == 0) asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,0] neg_lo:[1,0] neg_hi:[0,0]" : "=v"(r) : "v"(b), "v"(q));
+    else asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,1] neg_lo:[1,0] neg_hi:[0,0]" : "=v"(r) : "v"(b), "v"(q));
+    return r;
 }
 __device__ __forceinline__ float min3_abs(float a, float b, float c) { // min(a, |b|, |c|); NaNs drop out (IEEE minNum)
     float r;
@@ -240,8 +256,7 @@ __device__ __forceinline__ Hit8 intersect_ns8_v2(const Scene8 &sc, float ox, flo
         asm volatile(APT_R4(APT_T_OPS) : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(y0), "+v"(y1) : "v"(dy), "v"(dz));
     }
 #endif
-    auto update = [&](float t0, float t1, int k) {
-        const uint32_t m0 = f32_bits(t0) - kc.bias, m1 = f32_bits(t1) - kc.bias;
+    auto update_keys = [&](uint32_t m0, uint32_t m1, int k) {
         const uint32_t nb = min3_u32(best, m0, m1);
         const uint64_t better = __builtin_amdgcn_ballot_w64(nb != best); // strict '<': lowest index wins ties
         best = nb;
@@ -250,6 +265,9 @@ __device__ __forceinline__ Hit8 intersect_ns8_v2(const Scene8 &sc, float ox, flo
         b2 = (k & 4) ? (b2 | better) : (b2 & ~better);
         if (MODE == kModeOracle) any |= better;
     };
+    auto update = [&](float t0, float t1, int k) { update_keys(f32_bits(t0) - kc.bias, f32_bits(t1) - kc.bias, k); };
+    auto update64 = [&](uint64_t keys, int k) { update_keys((uint32_t)keys, (uint32_t)(keys >> 32), k); };
+    (void)update; (void)update64;
 #pragma unroll
     for (int k = 0; k < 8; k += 2) { // rt_helper.h:457-467, two spheres per packed instruction
         const HitPre2 h = intersect_pre2(f2{sc.cx[k], sc.cx[k + 1]}, f2{sc.cy[k], sc.cy[k + 1]}, f2{sc.cz[k], sc.cz[k + 1]},
@@ -260,9 +278,21 @@ __device__ __forceinline__ Hit8 intersect_ns8_v2(const Scene8 &sc, float ox, flo
         const f2 y = h.disc * r0, hh = r0 * 0.5f;
         const f2 res = __builtin_elementwise_fma(-y, y, h.disc);
         const f2 q = __builtin_elementwise_fma(res, hh, y);
+#if APT_KEY64
+        // Both keys of a sphere by ONE 64-bit add of (2^31 - bias, -bias) to its (-t0, t1) register pair (u(x) = bit pattern).
+        // Low half: u(-t0) + 2^31 - bias (mod 2^32) is key(t0) = u(t0) - bias when t0 > eps (u(-t0) = 2^31 + u(t0)); for every other
+        // t0 -- negative: u(|t0|) + 2^31 - bias; in [+0, eps]: 2^32 - (bias - u(t0)); NaN, inf -- it is >= key(kMissT), like the
+        // 32-bit form's invalid keys, so it can never win.  The low half carries into the high half exactly when t0 > eps (or is a
+        // sign-bit NaN / +inf, where t1 is NaN / inf too): the high half is then key(t1) + 1, but t1 >= t0 > eps, so key(t0) <=
+        // key(t1) < key(t1) + 1 with no wrap (key(t1) = 2^32 - 1 would mean t1 = eps), and min3 returns key(t0) either way.
+        // `best` therefore only ever holds a true key or the initial one, and tmin = value(best) as before.
+        update64(root_pair<0>(h.b, q) + kc.nbias2, k);
+        update64(root_pair<1>(h.b, q) + kc.nbias2, k + 1);
+#else
         const f2 t0 = h.b - q, t1 = h.b + q;
         update(t0.x, t1.x, k);
         update(t0.y, t1.y, k + 1);
+#endif
     }
     const float tmin = bits_f32(best + kc.bias);
     uint64_t light_mask; // lanes whose arg-min is the light
