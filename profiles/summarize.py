@@ -20,7 +20,7 @@ for f in sorted(glob.glob(f"{src}/pmc*/*/*_counter_collection.csv")):
             agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k, v in agg.items():
         pmc[k] = {"launches": len(v), "avg": sum(v) / len(v)}
-out = {"tag": tag, "command": "python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline",
+out = {"tag": tag, "command": "python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extra",
        "kernel": main["Name"], "calls": int(main["Calls"]), "avg_ns": float(main["AverageNs"]),
        "min_ns": float(main["MinNs"]), "max_ns": float(main["MaxNs"]), "pmc": pmc}
 if "GRBM_GUI_ACTIVE" in pmc:   # summed over the 8 XCDs (MI355X_MICROARCH.md, DVFS give-back)
