@@ -190,10 +190,13 @@ __device__ __forceinline__ void div3_packed(f2_t nxy, float nz, float d, f2_t &u
     e = __builtin_fmaf(-d, q, nz);
     uz = __builtin_fmaf(e, r, q);
 }
-// |numerators| and len2 >= 2^-96 (not -0, no scaling needed), len2 <= 2^60 and not NaN (d = sqrt(len2) <= 2^30).
+// The predicate the 8-sphere bounce block evaluates (pt_trace.h, kFastMin = 2^-29, NaN-propagating minimum): |numerators|
+// >= 2^-29 (not -0, no scaling needed, len2 >= 2^-58) and rsq(len2) >= 2^-29, i.e. len2 <= 2^58 up to the rsq's last ulp and
+// not NaN -- a subset of what the sequence is valid for (|numerators| and len2 >= 2^-96, len2 <= 2^60: d = sqrt(len2) <= 2^30).
 __device__ __forceinline__ bool div3_operands_ok(float len2, float nx, float ny, float nz) {
-    const float lo = fminf(fminf(fabsf(nx), fabsf(ny)), fminf(fabsf(nz), len2));
-    return lo >= 0x1p-96f && !(__float_as_uint(len2) > 0x5d800000u);
+    const float r0 = __builtin_amdgcn_rsqf(len2);
+    const float lo = fminf(fminf(fabsf(nx), fabsf(ny)), fminf(fabsf(nz), r0));
+    return lo >= 0x1p-29f && r0 == r0 && nx == nx && ny == ny && nz == nz;
 }
 #endif
 

@@ -800,6 +800,13 @@ __global__ __launch_bounds__(kBlock) void selftest_div3_kernel(uint64_t begin, u
 #if defined(__HIP_DEVICE_COMPILE__)
     const uint64_t stride = (uint64_t)gridDim.x * kBlock;
     unsigned long long bad = 0, first = ~0ull, accepted = 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {   // the validity chain's minimum must PROPAGATE NaN (v_minimum3_f32) and take |.|
+        const float qn = __uint_as_float(0x7fc00000u);
+        float one = 1.0f, a = -0.5f, b = 3.0f;
+        asm volatile("" : "+v"(one), "+v"(a), "+v"(b));
+        const float m0 = minimum3_abs(one, a, b), m1 = minimum3_abs(one, qn, b), m2 = minimum3_abs(one, b, -qn), m3 = minimum3_abs(qn, a, b);
+        if (!(m0 == 0.5f) || m1 == m1 || m2 == m2 || m3 == m3 || (m1 >= kFastMin) || !(m0 >= kFastMin)) { ++bad; first = 0; }
+    }
     for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < count; i += stride) {
         const uint64_t ctr = begin + i;
         uint64_t h = splitmix64(ctr);

@@ -201,6 +201,27 @@ __device__ __forceinline__ float min3_abs(float a, float b, float c) { // min(a,
     asm("v_min3_f32 %0, %1, |%2|, |%3|" : "=v"(r) : "v"(a), "v"(b), "v"(c));
     return r;
 }
+// The validity chain of the v2 bounce: min(a, |b|, |c|) that PROPAGATES NaN (v_minimum3_f32, IEEE 754-2019 minimum), so that
+// a NaN operand stays flagged, against ONE threshold kFastMin = 2^-29 for everything the fast sequences need:
+//   |discriminant| (sqrt_rn_rsq1 needs >= 2^-96), |nx|, |ny|, |nz| (div3 numerators: not -0, >= 2^-96; len2 >= 2^-58 then needs
+//   no test of its own), and rsq(len2) in place of len2 <= 2^60 (pt_core.h div3_operands_ok: rsq(len2) >= 2^-29 is len2 <= 2^58
+//   up to the rsq's last ulp, well inside 2^60; +inf / NaN give 0 / NaN).  A path that fails redoes the bounce exactly, so a
+//   stricter test only costs time: |component| < 2^-29 has probability ~1e-10 per bounce in these scenes.
+constexpr float kFastMin = 0x1p-29f;
+__device__ __forceinline__ float minimum3_abs(float a, float b, float c) {
+    float r;
+    asm("v_minimum3_f32 %0, %1, |%2|, |%3|" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+// The same when an operand was just written by a transcendental instruction (v_rsq_f32): gfx950 needs one wait state between
+// a TRANS result and a non-TRANS VALU instruction that reads it.  The compiler inserts it for its own instructions but does not
+// look into inline asm (measured: without the s_nop the minimum read the register's previous contents and ~2 % of the waves of
+// the sample-queue kernels took the exact path for nothing -- still bit-exact, the exact path always is).
+__device__ __forceinline__ float minimum3_abs_after_trans(float a, float b, float c) {
+    float r;
+    asm("s_nop 0\n\tv_minimum3_f32 %0, %1, |%2|, |%3|" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
 __device__ __forceinline__ uint32_t min3_u32(uint32_t a, uint32_t b, uint32_t c) {
     uint32_t r;
     asm("v_min3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
@@ -272,7 +293,7 @@ __device__ __forceinline__ Hit8 intersect_ns8_v2(const Scene8 &sc, float ox, flo
     for (int k = 0; k < 8; k += 2) { // rt_helper.h:457-467, two spheres per packed instruction
         const HitPre2 h = intersect_pre2(f2{sc.cx[k], sc.cx[k + 1]}, f2{sc.cy[k], sc.cy[k + 1]}, f2{sc.cz[k], sc.cz[k + 1]},
                                          f2{sc.r2[k], sc.r2[k + 1]}, ox, oy, oz, dx, dy, dz);
-        amin = min3_abs(amin, h.disc.x, h.disc.y);
+        amin = minimum3_abs(amin, h.disc.x, h.disc.y);
         // sqrt_rn_rsq1 on both lanes of the pair (pt_core.h): y = x*r, hh = r/2, q = fma(fma(-y,y,x), hh, y)
         const f2 r0 = {__builtin_amdgcn_rsqf(h.disc.x), __builtin_amdgcn_rsqf(h.disc.y)};
         const f2 y = h.disc * r0, hh = r0 * 0.5f;
@@ -304,6 +325,8 @@ __device__ __forceinline__ Hit8 intersect_ns8_v2(const Scene8 &sc, float ox, flo
         const uint32_t a0 = select_const(b0, 16), a1 = select_const(b1, 32), a2 = select_const(b2, 64);
         asm("v_or3_b32 %0, %1, %2, %3" : "=v"(addr) : "v"(a0), "v"(a1), "v"(a2));
     }
+    // (Deriving this mask from b0 / b1 / b2 on the SALU saves the compare but costs 6-8 more spilled SGPRs in every kernel:
+    // 21.89 against 21.84 ms at C2, +3 % on the sample-queue kernels -- measured in round 2, not kept.)
     light_mask = __builtin_amdgcn_ballot_w64(addr == (uint32_t)ta.light * 16u); // light < 0 or > 7 never matches
     if (MODE == kModeOracle) light_mask &= any;
     return Hit8{tmin, addr, light_mask};
@@ -342,11 +365,11 @@ __device__ __forceinline__ uint64_t bounce_ns8_v2(const Scene8 &sc, const Tab8 t
         acc = acc + nz * nz;
         len2 = acc;
     }
-    amin = min3_abs(amin, len2, nxy.x);            // sqrt_rn_rsq1's and div3_shared's validity, see pt_core.h
-    amin = min3_abs(amin, nxy.y, nz);
     float L;
     {
         const float r0 = __builtin_amdgcn_rsqf(len2);
+        amin = minimum3_abs_after_trans(amin, r0, nxy.x); // validity of the fast sqrt / divide sequences: see kFastMin
+        amin = minimum3_abs(amin, nxy.y, nz);
         const float y = len2 * r0, h = 0.5f * r0;
         const float r = __builtin_fmaf(-y, y, len2);
         L = __builtin_fmaf(r, h, y);
@@ -377,9 +400,7 @@ __device__ __forceinline__ uint64_t bounce_ns8_v2(const Scene8 &sc, const Tab8 t
     alive &= ~light_mask;
     n.alive = s.alive;
     albedo = Albedo{f2{col.x, col.y}, col.z};
-    const uint64_t tiny = __builtin_amdgcn_ballot_w64(amin < 0x1p-96f);
-    const uint64_t huge = __builtin_amdgcn_ballot_w64(f32_bits(len2) > 0x5d800000u); // len2 > 2^60 or NaN (len2 is never negative): see div3_shared
-    return tiny | huge;
+    return __builtin_amdgcn_ballot_w64(!(amin >= kFastMin)); // something too small, len2 > 2^60, or a NaN
 }
 
 // One bounce of a wave through the fast form, falling back to the exact form (sqrtf, '/', float selects) for the

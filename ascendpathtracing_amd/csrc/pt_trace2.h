@@ -72,13 +72,13 @@ __device__ __forceinline__ void bounce2_ns8(const Scene8 &sc, const Tab8 tab, co
         len2 = nx * nx + ny * ny;                                                  // :641-649 (0 + x^2 is x^2)
         len2 = len2 + nz * nz;
     }
-    aminA = min3_abs(aminA, len2.x, nx.x);      // validity of the fast sqrt / divide sequences (pt_core.h)
-    aminA = min3_abs(aminA, ny.x, nz.x);
-    aminB = min3_abs(aminB, len2.y, nx.y);
-    aminB = min3_abs(aminB, ny.y, nz.y);
     f2 L;
     {   // sqrt_rn_rsq1 on both paths
         const f2 r0 = {__builtin_amdgcn_rsqf(len2.x), __builtin_amdgcn_rsqf(len2.y)};
+        aminA = minimum3_abs_after_trans(aminA, r0.x, nx.x);    // validity of the fast sqrt / divide sequences: see kFastMin (pt_trace.h)
+        aminA = minimum3_abs(aminA, ny.x, nz.x);
+        aminB = minimum3_abs_after_trans(aminB, r0.y, nx.y);
+        aminB = minimum3_abs(aminB, ny.y, nz.y);
         const f2 y = len2 * r0, h = r0 * 0.5f;
         const f2 r = __builtin_elementwise_fma(-y, y, len2);
         L = __builtin_elementwise_fma(r, h, y);
@@ -112,8 +112,8 @@ __device__ __forceinline__ void bounce2_ns8(const Scene8 &sc, const Tab8 tab, co
     n.dx = s.dx - ux * k2; n.dy = s.dy - uy * k2; n.dz = s.dz - uz * k2;           // :699-704
     n.ox = hx; n.oy = hy; n.oz = hz;                                               // :706-708
     n.rx = ax * s.rx; n.ry = ay * s.ry; n.rz = az * s.rz;                          // :804-810 (albedo or 1)
-    redoA = __builtin_amdgcn_ballot_w64(aminA < 0x1p-96f) | __builtin_amdgcn_ballot_w64(f32_bits(len2.x) > 0x5d800000u); // len2 > 2^60 or NaN:
-    redoB = __builtin_amdgcn_ballot_w64(aminB < 0x1p-96f) | __builtin_amdgcn_ballot_w64(f32_bits(len2.y) > 0x5d800000u); // see div3_shared
+    redoA = __builtin_amdgcn_ballot_w64(!(aminA >= kFastMin)); // something too small, len2 > 2^60, or a NaN
+    redoB = __builtin_amdgcn_ballot_w64(!(aminB >= kFastMin));
 }
 
 // All bounces of both paths (full trace: no retirement, no roulette).  The hot loop has no merge with the exact
