@@ -183,6 +183,8 @@ __global__ __launch_bounds__(kBlock, TWO ? APT_TWO_WAVES : (RETIRE && SC == kSce
     Tab8 tab8{tab, tab + 8};
     if (NS8) tab8 = load_scene8(sph, sc, tab);
     else __syncthreads();
+    const bool planes = TWO && NS8 && scene8_shares_planes(sc);   // wave-uniform: the reference scene's axis-aligned walls (pt_trace.h)
+    (void)planes;
     const KeyConsts kc = make_key_consts(ta.eps);      // refill queue only (trace_ns8 makes its own)
     const bool fast_ok = eps_allows_rootkey(ta.eps);
 
@@ -228,7 +230,7 @@ __global__ __launch_bounds__(kBlock, TWO ? APT_TWO_WAVES : (RETIRE && SC == kSce
             pp.ox.y = rox; pp.oy.y = roy; pp.oz.y = roz; pp.dx.y = rdx; pp.dy.y = rdy; pp.dz.y = rdz;
         }
         pp.rx = pp.ry = pp.rz = f2{1.0f, 1.0f};
-        trace2_ns8<MODE>(sc, tab8, pp, ta);
+        trace2_ns8<MODE>(sc, tab8, pp, ta, planes);
         traced += 2 * ta.depth;
         return Col2{Col{pp.rx.x * gain.r, pp.ry.x * gain.g, pp.rz.x * gain.b}, Col{pp.rx.y * gain.r, pp.ry.y * gain.g, pp.rz.y * gain.b}};
     };

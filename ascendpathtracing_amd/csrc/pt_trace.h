@@ -43,6 +43,18 @@ constexpr int kStackSlots = kBlock / 8; // one pairwise-sum stack per sub-pixel 
 struct Scene8 { // wave-uniform registers (SGPRs)
     float cx[8], cy[8], cz[8], r2[8];
 };
+// Spheres that share a centre coordinate share every term that depends on that coordinate only (c - o, its product with the
+// ray direction, its square): computing such a term once is exact common-subexpression elimination, the same operation on
+// the same operands.  The six walls of the reference scene are axis-aligned giant spheres (gen_data.py:94-102): spheres
+// 2, 3, 4, 5 and 7 share cx, spheres 0-3 share cy, spheres 0, 1, 4, 5 and 7 share cz -- 13 distinct coordinates instead of
+// 24.  A scene table with that equality pattern (compared bit for bit, per wave, from the SGPR copy; any other table takes the
+// general form) is intersected through intersect_pre_planes(): 49 instead of 64 packed instructions for the 8 discriminants.
+__device__ __forceinline__ bool scene8_shares_planes(const Scene8 &sc) {
+    auto eq = [](float a, float b) { return f32_bits(a) == f32_bits(b); };
+    return eq(sc.cx[2], sc.cx[3]) && eq(sc.cx[2], sc.cx[4]) && eq(sc.cx[2], sc.cx[5]) && eq(sc.cx[2], sc.cx[7]) &&
+           eq(sc.cy[0], sc.cy[1]) && eq(sc.cy[0], sc.cy[2]) && eq(sc.cy[0], sc.cy[3]) &&
+           eq(sc.cz[0], sc.cz[1]) && eq(sc.cz[0], sc.cz[4]) && eq(sc.cz[0], sc.cz[5]) && eq(sc.cz[0], sc.cz[7]);
+}
 
 // LDS table of the 8-sphere scene: entry k of `geo` = (cx, cy, cz, r2), entry k of `alb` = (albedo, 0); 16 bytes per
 // entry, so that the byte offsets of entry k's index bits (16, 32, 64) are inline constants (bounce_ns8_v2).
@@ -96,6 +108,35 @@ __device__ __forceinline__ HitPre2 intersect_pre2(const float4 a, const float4 c
     return intersect_pre2(f2{a.x, a.y}, f2{a.z, a.w}, f2{c4.x, c4.y}, f2{c4.z, c4.w}, ox, oy, oz, dx, dy, dz);
 }
 
+
+// The 8 discriminants of a scene that passed scene8_shares_planes(), sphere pairs (0,1) (2,3) (4,5) (6,7) as intersect_pre2
+// returns them.  Distinct coordinates in register pairs:  X1 = (cx0, cx1)  X2 = (cx2, cx6)   Y1 = (cy4, cy5)  Y2 = (cy6, cy7)
+// Y3 = (cy0, cy0)   Z1 = (cz2, cz3)  Z2 = (cz0, cz6); every sum of a sphere pair finds both of its operands inside ONE pair per
+// source (op_sel picks the halves), so nothing is shuffled.  Operation for operation what intersect_pre2 computes per sphere.
+__device__ __forceinline__ void intersect_pre_planes(const Scene8 &sc, float ox, float oy, float oz, float dx, float dy, float dz,
+                                                     HitPre2 (&h)[4]) {
+    const f2 X1 = {sc.cx[0], sc.cx[1]}, X2 = {sc.cx[2], sc.cx[6]};
+    const f2 Y1 = {sc.cy[4], sc.cy[5]}, Y2 = {sc.cy[6], sc.cy[7]}, Y3 = {sc.cy[0], sc.cy[0]};
+    const f2 Z1 = {sc.cz[2], sc.cz[3]}, Z2 = {sc.cz[0], sc.cz[6]};
+    const f2 x1 = X1 - ox, x2 = X2 - ox, y1 = Y1 - oy, y2 = Y2 - oy, y3 = Y3 - oy, z1 = Z1 - oz, z2 = Z2 - oz;
+    auto lo = [](f2 v) { return f2{v.x, v.x}; };
+    auto swap = [](f2 v) { return f2{v.y, v.x}; };
+    {   // b = (ocx*dx + ocy*dy) + ocz*dz
+        const f2 px1 = x1 * dx, px2 = x2 * dx, py1 = y1 * dy, py2 = y2 * dy, py3 = y3 * dy, pz1 = z1 * dz, pz2 = z2 * dz;
+        h[0].b = (px1 + py3) + lo(pz2);
+        h[1].b = (lo(px2) + py3) + pz1;
+        h[2].b = (lo(px2) + py1) + lo(pz2);
+        h[3].b = (swap(px2) + py2) + swap(pz2);
+    }
+    {   // c = ((ocx^2 + ocy^2) + ocz^2) - r2;  disc = b*b - c
+        const f2 qx1 = x1 * x1, qx2 = x2 * x2, qy1 = y1 * y1, qy2 = y2 * y2, qy3 = y3 * y3, qz1 = z1 * z1, qz2 = z2 * z2;
+        f2 c0 = (qx1 + qy3) + lo(qz2), c1 = (lo(qx2) + qy3) + qz1, c2 = (lo(qx2) + qy1) + lo(qz2), c3 = (swap(qx2) + qy2) + swap(qz2);
+        c0 = c0 - f2{sc.r2[0], sc.r2[1]}; c1 = c1 - f2{sc.r2[2], sc.r2[3]};
+        c2 = c2 - f2{sc.r2[4], sc.r2[5]}; c3 = c3 - f2{sc.r2[6], sc.r2[7]};
+        h[0].disc = h[0].b * h[0].b - c0; h[1].disc = h[1].b * h[1].b - c1;
+        h[2].disc = h[2].b * h[2].b - c2; h[3].disc = h[3].b * h[3].b - c3;
+    }
+}
 
 // ---- trace: reference scene (Ns == 8) ----------------------------------------------------
 // One bounce: 8 intersections (sphere operands in SGPRs), arg-min, gather, shade.
@@ -255,7 +296,7 @@ __device__ __forceinline__ void apply_albedo(f2 &rxy, float &rz, const Albedo &a
 // The intersection half of a bounce: all 8 spheres against one ray, integer-key arg-min, -> nearest accepted root,
 // byte offset of the hit sphere's LDS table entry (index * 16) and the wave mask of the lanes that hit the light.
 struct Hit8 { float tmin; uint32_t addr; uint64_t light; };
-template <int MODE>
+template <int MODE, bool PLANES = false>
 __device__ __forceinline__ Hit8 intersect_ns8_v2(const Scene8 &sc, float ox, float oy, float oz, float dx, float dy, float dz,
                                                  const TraceArgs &ta, const KeyConsts &kc, float &amin) {
     uint32_t best = kc.init;
@@ -289,10 +330,13 @@ __device__ __forceinline__ Hit8 intersect_ns8_v2(const Scene8 &sc, float ox, flo
     auto update = [&](float t0, float t1, int k) { update_keys(f32_bits(t0) - kc.bias, f32_bits(t1) - kc.bias, k); };
     auto update64 = [&](uint64_t keys, int k) { update_keys((uint32_t)keys, (uint32_t)(keys >> 32), k); };
     (void)update; (void)update64;
+    HitPre2 hp[4];
+    if (PLANES) intersect_pre_planes(sc, ox, oy, oz, dx, dy, dz, hp);
 #pragma unroll
     for (int k = 0; k < 8; k += 2) { // rt_helper.h:457-467, two spheres per packed instruction
-        const HitPre2 h = intersect_pre2(f2{sc.cx[k], sc.cx[k + 1]}, f2{sc.cy[k], sc.cy[k + 1]}, f2{sc.cz[k], sc.cz[k + 1]},
-                                         f2{sc.r2[k], sc.r2[k + 1]}, ox, oy, oz, dx, dy, dz);
+        const HitPre2 h = PLANES ? hp[k / 2]
+                                 : intersect_pre2(f2{sc.cx[k], sc.cx[k + 1]}, f2{sc.cy[k], sc.cy[k + 1]}, f2{sc.cz[k], sc.cz[k + 1]},
+                                                  f2{sc.r2[k], sc.r2[k + 1]}, ox, oy, oz, dx, dy, dz);
         amin = minimum3_abs(amin, h.disc.x, h.disc.y);
         // sqrt_rn_rsq1 on both lanes of the pair (pt_core.h): y = x*r, hh = r/2, q = fma(fma(-y,y,x), hh, y)
         const f2 r0 = {__builtin_amdgcn_rsqf(h.disc.x), __builtin_amdgcn_rsqf(h.disc.y)};

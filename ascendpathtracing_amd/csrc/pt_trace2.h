@@ -42,13 +42,13 @@ __device__ __forceinline__ float sum3_f64(float p0, float p1, float p2) {
 // One bounce of both paths.  aliveA / aliveB: wave masks (in: before, out: after).  redoA / redoB: wave masks of
 // the lanes whose path A / B left the validity range of the fast sequences.  `ones_off`: byte offset, relative to the albedo
 // table, of an entry (1, 1, 1) -- a path that is no longer alive multiplies its throughput by it (x1 is exact).
-template <int MODE>
+template <int MODE, bool PLANES>
 __device__ __forceinline__ void bounce2_ns8(const Scene8 &sc, const Tab8 tab, const PathPair &s, PathPair &n,
                                             const TraceArgs &ta, const KeyConsts &kc, uint32_t ones_off,
                                             uint64_t &aliveA, uint64_t &aliveB, uint64_t &redoA, uint64_t &redoB) {
     float aminA = 1.0f, aminB = 1.0f; // per path: a finished path's request for the exact form can be ignored (trace2_ns8)
-    const Hit8 hA = intersect_ns8_v2<MODE>(sc, s.ox.x, s.oy.x, s.oz.x, s.dx.x, s.dy.x, s.dz.x, ta, kc, aminA);
-    const Hit8 hB = intersect_ns8_v2<MODE>(sc, s.ox.y, s.oy.y, s.oz.y, s.dx.y, s.dy.y, s.dz.y, ta, kc, aminB);
+    const Hit8 hA = intersect_ns8_v2<MODE, PLANES>(sc, s.ox.x, s.oy.x, s.oz.x, s.dx.x, s.dy.x, s.dz.x, ta, kc, aminA);
+    const Hit8 hB = intersect_ns8_v2<MODE, PLANES>(sc, s.ox.y, s.oy.y, s.oz.y, s.dx.y, s.dy.y, s.dz.y, ta, kc, aminB);
     aliveA &= ~hA.light;                    // rt_helper.h:773-787  alive &= idx != light
     aliveB &= ~hB.light;
     // centre and albedo of the two hit spheres: dword reads from the LDS table straight into (A, B) pairs
@@ -118,8 +118,8 @@ __device__ __forceinline__ void bounce2_ns8(const Scene8 &sc, const Tab8 tab, co
 
 // All bounces of both paths (full trace: no retirement, no roulette).  The hot loop has no merge with the exact
 // form and no state copies (two bounces per turn, ping-pong): see trace_ns8.
-template <int MODE>
-__device__ __forceinline__ void trace2_ns8(const Scene8 &sc, const Tab8 tab, PathPair &s, const TraceArgs &ta) {
+template <int MODE, bool PLANES>
+__device__ __forceinline__ void trace2_ns8_t(const Scene8 &sc, const Tab8 tab, PathPair &s, const TraceArgs &ta) {
     const KeyConsts kc = make_key_consts(ta.eps);
     uint32_t ones_off = 8 * 16; // the entry after the 8 albedos (load_scene8 writes it)
     asm volatile("" : "+v"(ones_off));
@@ -137,7 +137,7 @@ __device__ __forceinline__ void trace2_ns8(const Scene8 &sc, const Tab8 tab, Pat
     };
     auto step = [&](const PathPair &in, PathPair &out) -> bool { // true: the wave must go exact from `in`
         uint64_t oa = aliveA, ob = aliveB, redoA, redoB;
-        bounce2_ns8<MODE>(sc, tab, in, out, ta, kc, ones_off, oa, ob, redoA, redoB);
+        bounce2_ns8<MODE, PLANES>(sc, tab, in, out, ta, kc, ones_off, oa, ob, redoA, redoB);
         if (__builtin_expect((redoA | redoB) != 0, 0)) {
             // the request of a path that is already finished (alive bit cleared or throughput zero) is ignored: it cannot
             // reach any output any more (deep all-miss paths, |n| ~ 1e20, are of that kind)
@@ -159,6 +159,13 @@ __device__ __forceinline__ void trace2_ns8(const Scene8 &sc, const Tab8 tab, Pat
         if (__builtin_expect(step(s, n), 0)) { rest_exact(s, d); return; }
         s = n;
     }
+}
+
+// `planes`: scene8_shares_planes(sc), evaluated once per wave by the kernel (wave-uniform branch around two copies of the loop)
+template <int MODE>
+__device__ __forceinline__ void trace2_ns8(const Scene8 &sc, const Tab8 tab, PathPair &s, const TraceArgs &ta, bool planes) {
+    if (planes) trace2_ns8_t<MODE, true>(sc, tab, s, ta);
+    else trace2_ns8_t<MODE, false>(sc, tab, s, ta);
 }
 
 } // namespace
