@@ -113,7 +113,7 @@ __global__ __launch_bounds__(kBlock) void render_paths_queue_kernel(const float 
         const bool active = depth_left != 0;
         Albedo albedo;
         uint64_t alive_out = alive;
-        const uint64_t redo = bounce_ns8_v2<MODE>(sc, tab8, in, out, ta, kc, alive_out, albedo) & __builtin_amdgcn_ballot_w64(active);
+        const uint64_t redo = bounce_ns8_v2p<MODE>(sc, tab8, in, out, ta, kc, alive_out, albedo, sc.planes) & __builtin_amdgcn_ballot_w64(active);
         if (__builtin_expect(redo != 0, 0)) {
             const bool fin = select_const(alive, 1) == 0 || (thr_xy.x == 0.0f && thr_xy.y == 0.0f && thr_z == 0.0f);
             if (__any(select_const(redo, 1) != 0 && !fin)) return true;
@@ -183,7 +183,7 @@ __global__ __launch_bounds__(kBlock, TWO ? APT_TWO_WAVES : (RETIRE && SC == kSce
     Tab8 tab8{tab, tab + 8};
     if (NS8) tab8 = load_scene8(sph, sc, tab);
     else __syncthreads();
-    const bool planes = TWO && NS8 && scene8_shares_planes(sc);   // wave-uniform: the reference scene's axis-aligned walls (pt_trace.h)
+    const bool planes = NS8 && sc.planes;   // wave-uniform: the reference scene's axis-aligned walls (pt_trace.h)
     (void)planes;
     const KeyConsts kc = make_key_consts(ta.eps);      // refill queue only (trace_ns8 makes its own)
     const bool fast_ok = eps_allows_rootkey(ta.eps);
@@ -362,7 +362,7 @@ __global__ __launch_bounds__(kBlock, TWO ? APT_TWO_WAVES : (RETIRE && SC == kSce
                     const bool active = depth_left != 0;
                     Albedo albedo;
                     uint64_t alive_out = alive;
-                    const uint64_t redo = bounce_ns8_v2<MODE>(sc, tab8, cur, nxt, ta, kc, alive_out, albedo) & __builtin_amdgcn_ballot_w64(active);
+                    const uint64_t redo = bounce_ns8_v2p<MODE>(sc, tab8, cur, nxt, ta, kc, alive_out, albedo, sc.planes) & __builtin_amdgcn_ballot_w64(active);
                     if (__builtin_expect(redo != 0, 0)) { // a finished path's request is ignored, see trace_ns8
                         const bool fin = select_const(alive, 1) == 0 || (thr_xy.x == 0.0f && thr_xy.y == 0.0f && thr_z == 0.0f);
                         if (__any(select_const(redo, 1) != 0 && !fin)) return true;

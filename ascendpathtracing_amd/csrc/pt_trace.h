@@ -42,6 +42,7 @@ constexpr int kStackSlots = kBlock / 8; // one pairwise-sum stack per sub-pixel 
 
 struct Scene8 { // wave-uniform registers (SGPRs)
     float cx[8], cy[8], cz[8], r2[8];
+    bool planes; // scene8_shares_planes(), set by load_scene8()
 };
 // Spheres that share a centre coordinate share every term that depends on that coordinate only (c - o, its product with the
 // ray direction, its square): computing such a term once is exact common-subexpression elimination, the same operation on
@@ -376,11 +377,11 @@ __device__ __forceinline__ Hit8 intersect_ns8_v2(const Scene8 &sc, float ox, flo
     return Hit8{tmin, addr, light_mask};
 }
 
-template <int MODE>
+template <int MODE, bool PLANES = false>
 __device__ __forceinline__ uint64_t bounce_ns8_v2(const Scene8 &sc, const Tab8 tab, const PathState &s, PathState &n,
                                                   const TraceArgs &ta, const KeyConsts &kc, uint64_t &alive, Albedo &albedo) {
     float amin = 1.0f;
-    const Hit8 hit = intersect_ns8_v2<MODE>(sc, s.oxy.x, s.oxy.y, s.oz, s.dxy.x, s.dxy.y, s.dz, ta, kc, amin);
+    const Hit8 hit = intersect_ns8_v2<MODE, PLANES>(sc, s.oxy.x, s.oxy.y, s.oz, s.dxy.x, s.dxy.y, s.dz, ta, kc, amin);
     const float tmin = hit.tmin;
     const uint32_t addr = hit.addr;
     const uint64_t light_mask = hit.light;
@@ -447,6 +448,14 @@ __device__ __forceinline__ uint64_t bounce_ns8_v2(const Scene8 &sc, const Tab8 t
     return __builtin_amdgcn_ballot_w64(!(amin >= kFastMin)); // something too small, len2 > 2^60, or a NaN
 }
 
+// The same with the plane-sharing form of the intersections chosen at run time (scene8_shares_planes(), wave-uniform)
+template <int MODE>
+__device__ __forceinline__ uint64_t bounce_ns8_v2p(const Scene8 &sc, const Tab8 tab, const PathState &s, PathState &n, const TraceArgs &ta,
+                                                   const KeyConsts &kc, uint64_t &alive, Albedo &albedo, bool planes) {
+    return planes ? bounce_ns8_v2<MODE, true>(sc, tab, s, n, ta, kc, alive, albedo)
+                  : bounce_ns8_v2<MODE, false>(sc, tab, s, n, ta, kc, alive, albedo);
+}
+
 // One bounce of a wave through the fast form, falling back to the exact form (sqrtf, '/', float selects) for the
 // whole wave when a lane whose path can still reach an output left the fast sequences' validity range, or when
 // eps does not permit the integer root keys.  `alive` as in bounce_ns8_v2; s.alive is refreshed from it only on
@@ -459,7 +468,7 @@ __device__ __forceinline__ void bounce_ns8_checked(const Scene8 &sc, const Tab8 
     uint64_t redo = ~0ull;
     Albedo albedo;
     bool fast_stands = false;
-    if (__builtin_expect(fast_ok, 1)) { redo = bounce_ns8_v2<MODE>(sc, tab, s, n, ta, kc, alive, albedo); fast_stands = true; }
+    if (__builtin_expect(fast_ok, 1)) { redo = bounce_ns8_v2p<MODE>(sc, tab, s, n, ta, kc, alive, albedo, sc.planes); fast_stands = true; }
     if (__builtin_expect((redo & active) != 0, 0)) {
         // A lane left the validity range of the fast sequences (|sqrt argument| < 2^-96, divide operands outside
         // [2^-40, 2^40]).  A lane whose path is already finished (alive bit cleared or throughput zero) cannot
@@ -530,7 +539,7 @@ __device__ __forceinline__ uint32_t trace_ns8(const Scene8 &sc, const Tab8 tab, 
         auto step = [&](PathState &in, PathState &out, uint32_t d) -> bool {
             Albedo albedo;
             uint64_t alive_out = alive;
-            const uint64_t redo = bounce_ns8_v2<MODE>(sc, tab, in, out, ta, kc, alive_out, albedo);
+            const uint64_t redo = bounce_ns8_v2p<MODE>(sc, tab, in, out, ta, kc, alive_out, albedo, sc.planes);
             if (__builtin_expect(redo != 0, 0)) {
                 // A lane left the validity range of the fast sequences (|sqrt argument| < 2^-96, divide operands
                 // outside [2^-40, 2^40]).  A lane whose path is already finished (alive bit cleared or throughput
@@ -871,6 +880,7 @@ __device__ __forceinline__ Tab8 load_scene8(const float *__restrict__ sph, Scene
         tab[8 + k] = make_float4(sph[56 + k], sph[64 + k], sph[72 + k], 0.0f);
     }
     if (threadIdx.x == 8) tab[16] = make_float4(1.0f, 1.0f, 1.0f, 0.0f); // "albedo" of a path that is no longer alive (pt_trace2.h)
+    sc.planes = scene8_shares_planes(sc);
     __syncthreads();
     return Tab8{tab, tab + 8};
 }
