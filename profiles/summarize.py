@@ -8,12 +8,13 @@ import collections, csv, glob, json, os, shutil, sys
 tag = sys.argv[1]
 src = f"gpurun_out/prof_{tag}"
 here = os.path.dirname(os.path.abspath(__file__))
-stats = glob.glob(f"{src}/trace/*/*_kernel_stats.csv")[0]
+newest = lambda pat: max(glob.glob(pat), key=os.path.getmtime)   # gpurun merges runs into gpurun_out/: older passes may still lie there
+stats = newest(f"{src}/trace/*/*_kernel_stats.csv")
 shutil.copy(stats, f"{here}/{tag}_kernel_stats.csv")
 rows = list(csv.DictReader(open(stats)))
 main = max(rows, key=lambda r: float(r["TotalDurationNs"]))
 pmc = {}
-for f in sorted(glob.glob(f"{src}/pmc*/*/*_counter_collection.csv")):
+for f in sorted(newest(f"{d}/*/*_counter_collection.csv") for d in glob.glob(f"{src}/pmc[0-9]*") if os.path.isdir(d)):
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         if r["Kernel_Name"] == main["Name"]:
