@@ -4,6 +4,9 @@
 # starts the ranks as children before anything touches a GPU).  Writes <out>/rank<r>/ and prints one line per rank:
 # the band kernel's calls, average and total duration.
 #   bash profiles/run_profile_multi.sh N [out-dir] [extra bench.py flags]
+# With APT_PROF_PMC="<counters>" in the environment the ranks collect those counters instead (`--kernel-trace --pmc ...`, no
+# other tracing domain; one counter group per call, e.g. "FETCH_SIZE", then "WRITE_SIZE", then
+# "SQ_WAVES SQ_INSTS_VALU SQ_WAVE_CYCLES GRBM_GUI_ACTIVE") and the script prints per rank the per-launch averages for the band kernel.
 # On a one-GPU box this can only be rehearsed with APT_BENCH_SHARE_GPU=1 (ranks share the card, gloo instead of RCCL:
 # the durations then measure nothing).  North star: "rocprof ... at 1/2/4/8 GPUs" -- N = 1 is profiles/run_profile.sh.
 set -u
@@ -15,6 +18,9 @@ export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
 mkdir -p "$OUT"
 cat > "$OUT/rank.sh" <<'EOS'
 #!/bin/bash
+if [ -n "${APT_PROF_PMC:-}" ]; then
+  exec rocprofv3 --kernel-trace --pmc $APT_PROF_PMC --output-format csv -d "$APT_PROF_OUT/rank$RANK" -- python3 bench.py "$@"
+fi
 exec rocprofv3 --kernel-trace --stats --output-format csv -d "$APT_PROF_OUT/rank$RANK" -- python3 bench.py "$@"
 EOS
 chmod +x "$OUT/rank.sh"
@@ -25,7 +31,14 @@ grep '^{' "$OUT/bench.log" > "$OUT/bench.json" || true
 python3 - "$OUT" "$N" <<'EOP'
 import csv, glob, sys
 out, n = sys.argv[1], int(sys.argv[2])
+import collections
 for r in range(n):
+    for f in glob.glob(f"{out}/rank{r}/**/*counter_collection.csv", recursive=True):
+        agg = collections.defaultdict(list)
+        for row in csv.DictReader(open(f)):
+            if "render_frame_kernel" in row["Kernel_Name"]:
+                agg[row["Counter_Name"]].append(float(row["Counter_Value"]))
+        print(f"rank {r}: " + "  ".join(f"{k} {sum(v) / len(v):.6g} per launch ({len(v)} launches)" for k, v in sorted(agg.items())))
     for f in glob.glob(f"{out}/rank{r}/**/*kernel_stats.csv", recursive=True):
         for row in csv.DictReader(open(f)):
             if "render_frame_kernel" in row["Name"]:
