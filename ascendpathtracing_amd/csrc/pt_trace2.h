@@ -52,14 +52,28 @@ __device__ __forceinline__ void bounce2_ns8(const Scene8 &sc, const Tab8 tab, co
     aliveA &= ~hA.light;                    // rt_helper.h:773-787  alive &= idx != light
     aliveB &= ~hB.light;
     // centre and albedo of the two hit spheres: dword reads from the LDS table straight into (A, B) pairs
-    const char *geo = reinterpret_cast<const char *>(tab.geo), *alb = reinterpret_cast<const char *>(tab.alb);
-    auto ld = [](const char *base, uint32_t off) { return *reinterpret_cast<const float *>(base + off); };
+    const char *geo = reinterpret_cast<const char *>(tab.geo);
     uint32_t cA, cB; // albedo entry, or the (1,1,1) entry once the path is not alive (rt_helper.h:799-810: ret *= alive ? albedo : 1)
     asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(cA) : "v"(ones_off), "v"(hA.addr), "s"(aliveA));
     asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(cB) : "v"(ones_off), "v"(hB.addr), "s"(aliveB));
-    const f2 cx = {ld(geo, hA.addr), ld(geo, hB.addr)}, cy = {ld(geo, hA.addr + 4), ld(geo, hB.addr + 4)},
-             cz = {ld(geo, hA.addr + 8), ld(geo, hB.addr + 8)};
-    const f2 ax = {ld(alb, cA), ld(alb, cB)}, ay = {ld(alb, cA + 4), ld(alb, cB + 4)}, az = {ld(alb, cA + 8), ld(alb, cB + 8)};
+    // Twelve ds_read_b32 in one asm block, each landing in its half of an (A, B) pair.  Left to the compiler the reads of one
+    // path are merged into ds_read2_b32 -- an (x, y) pair of ONE path, which then costs six v_mov per pair-bounce (VALU slots) to
+    // shuffle into the (A, B) layout; LDS issue is not what binds this kernel.  The block waits for its own reads (the
+    // compiler's s_waitcnt insertion does not see them); the other waves of the SIMD cover the latency.
+    const uint32_t gA = (uint32_t)(uintptr_t)geo + hA.addr, gB = (uint32_t)(uintptr_t)geo + hB.addr;
+    const uint32_t aA = (uint32_t)(uintptr_t)geo + cA, aB = (uint32_t)(uintptr_t)geo + cB; // + 128 below: alb = geo + 8 entries (load_scene8)
+    float cxA, cyA, czA, cxB, cyB, czB, axA, ayA, azA, axB, ayB, azB;
+    asm volatile("ds_read_b32 %0, %12\n ds_read_b32 %1, %12 offset:4\n ds_read_b32 %2, %12 offset:8\n"
+                 "ds_read_b32 %3, %13\n ds_read_b32 %4, %13 offset:4\n ds_read_b32 %5, %13 offset:8\n"
+                 "ds_read_b32 %6, %14 offset:128\n ds_read_b32 %7, %14 offset:132\n ds_read_b32 %8, %14 offset:136\n"
+                 "ds_read_b32 %9, %15 offset:128\n ds_read_b32 %10, %15 offset:132\n ds_read_b32 %11, %15 offset:136\n"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(cxA), "=&v"(cyA), "=&v"(czA), "=&v"(cxB), "=&v"(cyB), "=&v"(czB), "=&v"(axA), "=&v"(ayA), "=&v"(azA),
+                   "=&v"(axB), "=&v"(ayB), "=&v"(azB)
+                 : "v"(gA), "v"(gB), "v"(aA), "v"(aB)
+                 : "memory");
+    const f2 cx = {cxA, cxB}, cy = {cyA, cyB}, cz = {czA, czB};
+    const f2 ax = {axA, axB}, ay = {ayA, ayB}, az = {azA, azB};
     // GenerateNewRays, rt_helper.h:504-709 (see bounce_ns8_v2 for the single-path form)
     const f2 t = {hA.tmin, hB.tmin};
     const f2 hx = s.ox + s.dx * t, hy = s.oy + s.dy * t, hz = s.oz + s.dz * t;   // :513-518
