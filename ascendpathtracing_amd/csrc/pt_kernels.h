@@ -4,6 +4,7 @@
 #pragma once
 #include "pt_trace.h"
 #include "pt_trace2.h"
+#include "pt_queue.h"
 
 namespace {
 
@@ -151,14 +152,7 @@ __global__ __launch_bounds__(kBlock) void render_paths_queue_kernel(const float 
 }
 
 // ---- kernel: fused frame ----------------------------------------------------------------
-struct FrameArgs {
-    Camera cam;
-    uint32_t width, height, samples;
-    uint64_t seed;
-    uint64_t pixel_begin, pixel_count;
-    float *fb;       // [3][pixel_count]
-    uint8_t *fb_u8;  // [pixel_count][3] or null
-};
+// FrameArgs: pt_queue.h
 
 // GROUP lanes share one sub-pixel: lane j of the group owns numpy's pairwise accumulator
 // r[j] (samples j, 8+j, 16+j, ...), so the summation order of np.mean is reproduced with

@@ -1,0 +1,379 @@
+// pt_queue.h -- the fused frame kernel with active-ray compaction for the reference's 8-sphere scene
+// (APT_FLAG_RETIRE, samples >= 8): render_frame_queue8_kernel.  Included by pt_kernels.h.
+//
+// Round 3 rewrite of the wave-level sample queue (round 2: one ray slot per lane in registers, ray-generate for the
+// whole wave whenever >= 32 lanes had an empty slot, the queue drained at every pairwise leaf; the flag returned
+// 55-60 % of the work it removed).  What a wave does now:
+//
+//   * it owns `ppw` consecutive pixels and works through their samples as ONE stream of items (a "unit" = one
+//     pairwise leaf of one pixel = 4 sub-pixels x n <= 128 samples); nothing is drained between units, so the only
+//     idle lanes are those of the wave's very last unit;
+//   * ray-generate (float64, ~230 VALU instructions per ray) is decoupled from tracing through a per-wave LDS RAY
+//     POOL (128 entries x 32 bytes, FIFO): whenever 64 entries are free the wave generates 64 consecutive items with
+//     all 64 lanes, whatever the lanes' paths are doing;
+//   * after every bounce the lanes whose path is finished (alive bit cleared, throughput zero, depth reached: wave
+//     masks on the scalar unit) park their throughput in the unit's colour buffer in LDS and take the next pool
+//     entries: ballot -> mbcnt rank -> one exec-masked block of ds_reads straight into the path-state registers;
+//     9 VALU instructions per bounce for the whole refill, none for parking;
+//   * a unit whose items have all been parked (one LDS counter per colour buffer, bumped by the parking lanes) is
+//     summed exactly as numpy's pairwise np.mean does it -- lane (sub, j) adds samples j, 8+j, ... in order, 3-step
+//     butterfly, the n % 8 tail in order, leaves combined through a stack -- by the lanes of the wave, then
+//     decoded (data_visualization.py:36-57).  Colour buffers form a ring of `nbuf` units, so tracing unit u+1 overlaps
+//     the stragglers of unit u.
+//
+// The arithmetic of a bounce is bounce_ns8_v2 (pt_trace.h), the accumulation order is numpy's: the frame is bit-identical
+// to the full-trace kernel's and to the CPU restatement's, and the traced-segment count equals the oracle's.
+#pragma once
+#include <type_traits>
+
+#include "pt_trace.h"
+
+namespace {
+
+struct FrameArgs {
+    Camera cam;
+    uint32_t width, height, samples;
+    uint64_t seed;
+    uint64_t pixel_begin, pixel_count;
+    float *fb;       // [3][pixel_count]
+    uint8_t *fb_u8;  // [pixel_count][3] or null
+};
+
+constexpr uint32_t kPool = 128;          // ray pool entries per wave (power of two)
+constexpr uint32_t kPoolBatch = 64;      // rays generated at a time: one per lane
+struct QueueArgs {
+    uint32_t ppw;        // pixels per wave
+    uint32_t nbuf;       // colour buffers = units that may be in flight (>= 2)
+    uint32_t buf_bytes;  // bytes per colour buffer: 4 * maxleaf * 12
+};
+// LDS of render_frame_queue8_kernel (all of it dynamic, so that the ray pool sits at LDS address 0 and a pool entry's address
+// needs no base added), in bytes from its start: pool_a | pool_b | scene table | camera | roulette keys | counters | stack | colours
+static_assert(kPool * 16u == 2048u, "the refill block's ds_read offsets assume pool_b at byte 2048");
+__host__ __device__ inline uint32_t queue_lds_off_tab() { return 2u * kPool * 16u; }
+__host__ __device__ inline uint32_t queue_lds_off_cam() { return queue_lds_off_tab() + (uint32_t)kTab8Floats4 * 16u; }
+__host__ __device__ inline uint32_t queue_lds_off_key() { return queue_lds_off_cam() + (uint32_t)sizeof(Camera); }
+__host__ __device__ inline uint32_t queue_lds_off_cnt(bool rr) { return queue_lds_off_key() + (rr ? kPool * 8u : 0u); }
+__host__ __device__ inline uint32_t queue_lds_off_stack(bool rr, uint32_t nbuf) { return queue_lds_off_cnt(rr) + ((nbuf * 4u + 15u) & ~15u); }
+__host__ __device__ inline uint32_t queue_lds_off_colq(bool rr, uint32_t nbuf, bool stack) {
+    return queue_lds_off_stack(rr, nbuf) + (stack ? (uint32_t)kMaxStack * 3u * 4u * 4u : 0u);
+}
+__host__ __device__ inline uint32_t queue_lds_bytes(bool rr, uint32_t nbuf, bool stack, uint32_t buf_bytes) {
+    return queue_lds_off_colq(rr, nbuf, stack) + nbuf * buf_bytes;
+}
+
+#ifndef APT_QUEUE8_WAVES
+#define APT_QUEUE8_WAVES 4 // waves per SIMD the register budget of render_frame_queue8_kernel is set for (its LDS allows 15 waves per CU at S = 64)
+#endif
+template <int MODE>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(APT_QUEUE8_WAVES, APT_QUEUE8_WAVES))) void render_frame_queue8_kernel(const float *__restrict__ sph, FrameArgs fa, TraceArgs ta,
+                                                                 LeafProg lp, QueueArgs qa) {
+    extern __shared__ __align__(16) unsigned char qlds[];
+    float4 *tab = reinterpret_cast<float4 *>(qlds + queue_lds_off_tab());
+    Camera &cam = *reinterpret_cast<Camera *>(qlds + queue_lds_off_cam());
+    const uint32_t lane = threadIdx.x;
+    // No static LDS in this kernel, so the dynamic region starts at LDS address 0 (tests/test_isa_hazards.py checks the kernel
+    // descriptor's group_segment_fixed_size); a build that breaks this renders nothing rather than reading the wrong pool entries.
+    if ((uint32_t)(uintptr_t)qlds != 0u) return;
+    if (lane < sizeof(Camera) / sizeof(double)) (&cam.pos[0])[lane] = (&fa.cam.pos[0])[lane];
+    Scene8 sc;
+    const Tab8 tab8 = load_scene8(sph, sc, tab); // ends with a barrier
+    const KeyConsts kc = make_key_consts(ta.eps);
+    const bool fast_ok = eps_allows_rootkey(ta.eps);
+    const bool rr = ta.rr_start != 0;
+    const uint32_t nleaves = lp.nleaves, S = fa.samples, H = fa.height;
+    const uint32_t nbuf = qa.nbuf;
+
+    float4 *pool_a = reinterpret_cast<float4 *>(qlds);                 // (ox, oy, dx, dy)
+    float4 *pool_b = pool_a + kPool;                                   // (oz, dz, colour address, counter address)
+    uint64_t *pool_key = reinterpret_cast<uint64_t *>(qlds + queue_lds_off_key());       // Russian-roulette key (APT_FLAG_RR only)
+    uint32_t *cnt = reinterpret_cast<uint32_t *>(qlds + queue_lds_off_cnt(rr));          // parked items per colour buffer
+    float *stack = reinterpret_cast<float *>(qlds + queue_lds_off_stack(rr, nbuf));      // [kMaxStack][3][4] when nleaves > 1
+    const uint32_t colq_off = queue_lds_off_colq(rr, nbuf, nleaves > 1);
+    unsigned char *colq = qlds + colq_off;                              // [nbuf][items][3] floats
+    constexpr uint32_t qlds_base = 0u;                                  // LDS byte address of the dynamic region (checked above)
+    if (lane < nbuf) cnt[lane] = 0u;
+    __syncthreads();
+
+    // this wave's pixels
+    const uint64_t wb = (uint64_t)blockIdx.x * qa.ppw;
+    const uint32_t npx = (uint32_t)min((uint64_t)qa.ppw, fa.pixel_count - wb);
+    const uint32_t U = npx * nleaves;                                   // units of this wave
+    const uint64_t q0 = fa.pixel_begin + wb;
+
+    // ---- wave-uniform queue state -------------------------------------------------------------------------------
+    uint32_t pool_head = 0, pool_level = 0;                             // FIFO ring: entries [head, head + level)
+    uint32_t g_unit = 0, g_off = 0, g_leaf = 0, g_start = 0, g_px = 0, g_buf = 0; // ray-generate cursor
+    uint32_t g_pi = (uint32_t)(q0 / H), g_pj = (uint32_t)(q0 % H);
+    uint32_t a_unit = 0, a_leaf = 0, a_px = 0, a_buf = 0, a_sp = 0;     // accumulation cursor (units are summed in order)
+    uint64_t active = 0, alive = 0;                                     // lanes with a running path / that has not hit the light
+    uint32_t iter = 0;                                                  // bounces executed by this wave so far
+    uint32_t traced = 0, n_bounce_exec = 0, n_gen_exec = 0, n_exact = 0; // statistics
+
+    // ---- per-lane path state ------------------------------------------------------------------------------------
+    PathState s;
+    path_init(s, 0.f, 0.f, 0.f, 0.f, 0.f, 1.f);
+    f2 thr_xy = {1.0f, 1.0f};
+    float thr_z = 1.0f;
+    uint32_t caddr = qlds_base + colq_off, cntaddr = qlds_base + queue_lds_off_cnt(rr); // LDS addresses of the item's colour / its buffer's counter
+    uint32_t stop = 0;                                                  // value of `iter` at which the path has done `depth` bounces
+    uint64_t key = 0;                                                   // Russian-roulette key of the running path
+
+    const Gain3 gain = load_gain(sph, ta);
+
+    // ---- ray-generate: the next <= 64 items of the current unit into the pool ---------------------------------------
+    auto gen_batch = [&]() __attribute__((always_inline)) {
+        ++n_gen_exec;
+        const uint32_t nl = lp.len(g_leaf), items = 4u * nl;
+        const uint32_t nb = min(kPoolBatch, items - g_off);
+        const bool on = lane < nb;
+        const uint32_t i = g_off + (on ? lane : 0u);                    // item within the unit: sub * nl + k
+        const uint32_t sub = (i >= nl ? 1u : 0u) + (i >= 2u * nl ? 1u : 0u) + (i >= 3u * nl ? 1u : 0u);
+        const uint32_t k = i - sub * nl;
+        const uint64_t path = ((q0 + g_px) * 4u + sub) * S + g_start + k; // gen_data.py:32-36
+        double u1, u2;
+        path_uniforms(fa.seed, path, u1, u2);
+        float rox, roy, roz, rdx, rdy, rdz;
+        camera_ray(cam, fa.width, fa.height, g_pi, g_pj, sub >> 1, sub & 1u, u1, u2, rox, roy, roz, rdx, rdy, rdz);
+        const uint32_t e = (pool_head + pool_level + lane) & (kPool - 1u);
+        if (on) {
+            pool_a[e] = make_float4(rox, roy, rdx, rdy);
+            pool_b[e] = make_float4(roz, rdz, __uint_as_float(qlds_base + colq_off + g_buf * qa.buf_bytes + i * 12u),
+                                    __uint_as_float(qlds_base + queue_lds_off_cnt(rr) + g_buf * 4u));
+            if (rr) pool_key[e] = rr_path_key(ta.seed, path);
+        }
+        pool_level += nb;
+        g_off += nb;
+        if (g_off == items) {                                           // next unit: next leaf of the pixel, or the next pixel
+            g_off = 0; ++g_unit; g_start += nl;
+            if (++g_buf == nbuf) g_buf = 0;
+            if (++g_leaf == nleaves) {
+                g_leaf = 0; g_start = 0; ++g_px;
+                if (++g_pj == H) { g_pj = 0; ++g_pi; }
+            }
+        }
+        __syncthreads(); // one wave per workgroup: orders the pool writes before the reads of other lanes
+    };
+
+    // ---- sum the oldest unit (all of its items are parked) as np.mean does; decode after the pixel's last leaf ------
+    auto accumulate_unit = [&]() __attribute__((always_inline)) {
+        __syncthreads();
+        const uint32_t nl = lp.len(a_leaf), nfull = nl & ~7u, nt = nl - nfull;
+        const uint32_t sub = (lane >> 3) & 3u, j = lane & 7u;          // lanes 32..63 repeat the work of lanes 0..31
+        const float *col = reinterpret_cast<const float *>(colq + a_buf * qa.buf_bytes);
+        const uint32_t base = (sub * nl + j) * 3u;
+        float acc[3];
+        acc[0] = col[base] * gain.r; acc[1] = col[base + 1] * gain.g; acc[2] = col[base + 2] * gain.b; // render.cpp:194-196
+        for (uint32_t i8 = 8; i8 < nfull; i8 += 8) {                    // numpy's chain r[j] += a[j + 8m]
+            const uint32_t o = base + i8 * 3u;
+            acc[0] = acc[0] + col[o] * gain.r; acc[1] = acc[1] + col[o + 1] * gain.g; acc[2] = acc[2] + col[o + 2] * gain.b;
+        }
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {                                // ((r0+r1)+(r2+r3)) + ((r4+r5)+(r6+r7))
+            float v = acc[ch];
+            v = v + __shfl_xor(v, 1, 64);
+            v = v + __shfl_xor(v, 2, 64);
+            v = v + __shfl_xor(v, 4, 64);
+            acc[ch] = v;
+        }
+        if (nt) {                                                       // res += a[i] for the n % 8 trailing samples, in order
+            const uint32_t o = (sub * nl + nfull + (j < nt ? j : 0u)) * 3u;
+            const float cr = col[o] * gain.r, cg = col[o + 1] * gain.g, cb = col[o + 2] * gain.b;
+            for (uint32_t t = 0; t < nt; ++t) {
+                const int src = (int)((lane & ~7u) + t);
+                acc[0] = acc[0] + __shfl(cr, src, 64);
+                acc[1] = acc[1] + __shfl(cg, src, 64);
+                acc[2] = acc[2] + __shfl(cb, src, 64);
+            }
+        }
+        float res[3] = {acc[0], acc[1], acc[2]};
+        if (nleaves > 1) {                                              // pairwise(left) + pairwise(right), innermost first
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) stack[(a_sp * 3 + ch) * 4 + sub] = acc[ch]; // the lanes of a group hold equal values
+            ++a_sp;
+            for (uint32_t m = 0; m < lp.ncomb(a_leaf); ++m) {
+                --a_sp;
+#pragma unroll
+                for (int ch = 0; ch < 3; ++ch) {
+                    const float x = stack[((a_sp - 1) * 3 + ch) * 4 + sub], y = stack[(a_sp * 3 + ch) * 4 + sub];
+                    stack[((a_sp - 1) * 3 + ch) * 4 + sub] = x + y;
+                }
+            }
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) res[ch] = stack[ch * 4 + sub];
+        }
+        if (a_leaf + 1 == nleaves) {                                    // decode_color: data_visualization.py:36-57
+            const float fs = (float)S;
+            const uint64_t pl = wb + a_px;
+            const int gbase = (int)(lane & ~31u);
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) {
+                const float mean = res[ch] / fs;                        // np.mean: float32 sum / count
+                double a64 = 0.0;                                       // :38 sum_color = zeros (float64)
+#pragma unroll
+                for (int sq = 0; sq < 4; ++sq) a64 = a64 + (double)__shfl(mean, gbase + sq * 8, 64); // :41-45
+                const double v = a64 / 4;                               // :46
+                const double cl = v < 0 ? 0 : (v > 1 ? 1 : v);          // :54
+                if (lane == 0) {
+                    fa.fb[(uint64_t)ch * fa.pixel_count + pl] = (float)cl;
+                    if (fa.fb_u8) fa.fb_u8[pl * 3 + ch] = (uint8_t)(cl * 255); // :55-57 truncation
+                }
+            }
+            a_sp = 0;
+        }
+        if (lane == 0) cnt[a_buf] = 0u;
+        ++a_unit;
+        if (++a_buf == nbuf) a_buf = 0;
+        if (++a_leaf == nleaves) { a_leaf = 0; ++a_px; }
+        __syncthreads();
+    };
+    auto oldest_unit_parked = [&]() __attribute__((always_inline)) -> bool { // uniform LDS read; a_unit < g_unit (the unit has been generated completely)
+        const uint32_t c = (uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&cnt[a_buf], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+        return c == 4u * lp.len(a_leaf);
+    };
+
+    // ---- after a bounce: finished paths park their throughput (the colour is throughput * gain, applied when summed) ----
+    auto park = [&]() __attribute__((always_inline)) {
+        const uint32_t orbits = f32_bits(thr_xy.x) | f32_bits(thr_xy.y) | f32_bits(thr_z);   // all three +-0 <=> the OR is +-0
+        const uint64_t zero = __builtin_amdgcn_ballot_w64(bits_f32(orbits) == 0.0f);
+        const uint64_t at_depth = __builtin_amdgcn_ballot_w64(stop == iter);
+        uint64_t done = active & (~alive | zero | at_depth);
+        {   // executed even when no lane is done (exec = 0 then: nothing happens), which keeps the control flow of the hot loop flat
+            uint64_t saved;
+            const uint32_t one = 1u;
+            asm volatile("s_and_saveexec_b64 %[sv], %[m]\n\t"
+                         "ds_write_b32 %[ca], %[rx]\n\t"
+                         "ds_write_b32 %[ca], %[ry] offset:4\n\t"
+                         "ds_write_b32 %[ca], %[rz] offset:8\n\t"
+                         "ds_add_u32 %[cn], %[one]\n\t"
+                         "s_mov_b64 exec, %[sv]"
+                         : [sv] "=&s"(saved)
+                         : [m] "s"(done), [ca] "v"(caddr), [rx] "v"(thr_xy.x), [ry] "v"(thr_xy.y), [rz] "v"(thr_z), [cn] "v"(cntaddr), [one] "v"(one)
+                         : "scc", "memory");
+            active &= ~done;
+        }
+    };
+    // ---- idle lanes take the next pool entries, in pool order, straight into the state registers `st` --------------------
+    auto refill = [&](PathState &st) __attribute__((always_inline)) {
+        const uint64_t want = ~active;
+        {   // no branch around this either: with nothing wanted or an empty pool `take` is 0
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(want >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)want, 0u));
+            const uint64_t take = want & __builtin_amdgcn_ballot_w64(rank < pool_level);
+            const uint32_t ea = qlds_base + (((pool_head + rank) << 4) & ((kPool - 1u) << 4));
+            const uint32_t new_stop = iter + ta.depth;
+            uint64_t saved;
+            asm volatile("s_and_saveexec_b64 %[sv], %[m]\n\t"
+                         "ds_read_b64 %[oxy], %[ea]\n\t"
+                         "ds_read_b64 %[dxy], %[ea] offset:8\n\t"
+                         "ds_read_b32 %[oz], %[ea] offset:2048\n\t"
+                         "ds_read_b32 %[dz], %[ea] offset:2052\n\t"
+                         "ds_read_b32 %[ca], %[ea] offset:2056\n\t"
+                         "ds_read_b32 %[cn], %[ea] offset:2060\n\t"
+                         "v_pk_add_f32 %[rxy], 1.0, 0 op_sel_hi:[0,0]\n\t"
+                         "v_mov_b32 %[rz], 1.0\n\t"
+                         "v_mov_b32 %[st], %[ns]\n\t"
+                         "s_waitcnt lgkmcnt(0)\n\t"
+                         "s_mov_b64 exec, %[sv]"
+                         : [sv] "=&s"(saved), [oxy] "+v"(st.oxy), [dxy] "+v"(st.dxy), [oz] "+v"(st.oz), [dz] "+v"(st.dz), [ca] "+v"(caddr),
+                           [cn] "+v"(cntaddr), [rxy] "+v"(thr_xy), [rz] "+v"(thr_z), [st] "+v"(stop)
+                         : [m] "s"(take), [ea] "v"(ea), [ns] "s"(new_stop)
+                         : "scc", "memory");
+            if (rr) {
+                const uint32_t e = ((pool_head + rank) & (kPool - 1u));
+                if (select_const(take, 1) != 0) key = pool_key[e];
+            }
+            const uint32_t nt = min((uint32_t)__popcll(want), pool_level);
+            pool_head = (pool_head + nt) & (kPool - 1u);
+            pool_level -= nt;
+            active |= take;
+            alive |= take;
+        }
+    };
+    // ---- bookkeeping after a bounce that stands ------------------------------------------------------------------
+    auto post_bounce = [&]() __attribute__((always_inline)) {
+        ++n_bounce_exec;
+        traced += (uint32_t)__popcll(active);
+        if (rr) {   // roulette after shading bounce d (0-based) when d + 1 >= rr_start; d = iter - (stop - depth)
+            const uint32_t d = iter - (stop - ta.depth);
+            const bool on = select_const(active, 1) != 0 && d + 1u >= ta.rr_start;
+            if (on) {
+                PathState t;
+                t.rxy = thr_xy; t.rz = thr_z; t.alive = select_const(alive, 1);
+                russian_roulette(t, key, d);
+                thr_xy = t.rxy; thr_z = t.rz;
+            }
+        }
+        ++iter;
+    };
+    // One bounce of the wave, in place.  Idle lanes compute on stale state: whatever they hold is overwritten when they take
+    // their next ray.  When a lane whose path can still reach an output leaves the validity range of the fast sequences
+    // (about 1e-5 of the wave-bounces), the bounce is redone for the whole wave with sqrtf() and '/' in a cold block.
+    auto step = [&](PathState &st, auto planes_tag) __attribute__((always_inline)) {
+        constexpr bool PLANES = decltype(planes_tag)::value;
+        PathState nx;
+        Albedo albedo;
+        uint64_t alive_out = alive;
+        bool redo_any = !fast_ok;
+        if (__builtin_expect(fast_ok, 1)) {
+            const uint64_t redo = bounce_ns8_v2<MODE, PLANES>(sc, tab8, st, nx, ta, kc, alive_out, albedo) & active;
+            if (__builtin_expect(redo != 0, 0)) { // a finished path's request is ignored (trace_ns8)
+                const bool fin = select_const(alive, 1) == 0 || (thr_xy.x == 0.0f && thr_xy.y == 0.0f && thr_z == 0.0f);
+                redo_any = __builtin_amdgcn_ballot_w64(select_const(redo, 1) != 0 && !fin) != 0; // (ballot: uniform for the compiler, __any is not)
+            }
+        }
+        if (__builtin_expect(redo_any, 0)) {
+            ++n_exact;
+            PathState c = st, o;
+            c.rxy = thr_xy; c.rz = thr_z; c.alive = select_const(alive, 1);
+            (void)bounce_ns8<MODE, false>(sc, tab8, c, o, ta);
+            nx.oxy = o.oxy; nx.oz = o.oz; nx.dxy = o.dxy; nx.dz = o.dz;
+            thr_xy = o.rxy; thr_z = o.rz;
+            alive = __builtin_amdgcn_ballot_w64(o.alive != 0);
+        } else {
+            apply_albedo(thr_xy, thr_z, albedo, alive_out);
+            alive = alive_out;
+        }
+        st.oxy = nx.oxy; st.oz = nx.oz; st.dxy = nx.dxy; st.dz = nx.dz;
+        post_bounce();
+    };
+
+    // Full service between two bounces: park, make room / generate when 64 pool entries are free, refill into `st`.
+    // -> true when the wave is finished: no lane got a ray although everything was offered, i.e. every unit has been
+    // generated, issued and parked.  (If no lane is active and the pool is empty, every generated item is parked, so the oldest
+    // unit can be summed and its buffer reused: generation is never blocked in that state.)
+    auto service_full = [&](PathState &st) __attribute__((always_inline)) -> bool {
+        park();
+        if (pool_level <= kPool - kPoolBatch && g_unit < U) {
+            bool room = g_off != 0 || g_unit - a_unit < nbuf;           // a unit needs a free colour buffer to start
+            if (!room && oldest_unit_parked()) { accumulate_unit(); room = true; }
+            if (room) gen_batch();
+        }
+        refill(st);
+        return active == 0;
+    };
+    // The hot loop: two bounces per turn, ray-generate / unit sums only in the first service.
+    // `guard`: an upper bound of the loop turns a wave can need (every turn either bounces an active lane or issues rays),
+    // so that a logic error can never leave a wave spinning on the GPU.
+    uint32_t guard = (uint32_t)min(2ull * ((uint64_t)npx * 4u * S * ((uint64_t)ta.depth + 1u) + 64u), 0xffffffffull);
+    auto run = [&](auto planes_tag) __attribute__((always_inline)) {
+        for (;;) {
+            if (service_full(s) || guard-- == 0u) break;
+            step(s, planes_tag);
+            park();                                                     // light service: no ray-generate here
+            refill(s);
+            step(s, planes_tag);
+        }
+    };
+    if (sc.planes) run(std::true_type{});
+    else run(std::false_type{});
+    // No lane is active, the pool is empty and every unit has been generated: every item is parked.
+    while (a_unit < U) accumulate_unit();
+
+    if (ta.traced && lane == 0) {
+        atomicAdd(ta.traced, (unsigned long long)traced);
+        atomicAdd(ta.traced + 1, 64ull * n_bounce_exec);
+        atomicAdd(ta.traced + 2, 64ull * n_gen_exec);
+        if (n_exact) atomicAdd(ta.traced + 3, (unsigned long long)n_exact);
+    }
+}
+
+} // namespace

@@ -168,6 +168,26 @@ int do_render_frame(const apt_context::Values &cv, const apt_render_params *p, v
     fa.width = p->width; fa.height = p->height; fa.samples = p->samples; fa.seed = p->seed;
     fa.pixel_begin = pixel_begin; fa.pixel_count = pixel_count; fa.fb = fb; fa.fb_u8 = fb_u8;
     const bool retire = p->flags & APT_FLAG_RETIRE;
+    if (retire && ns8 && group == 8 && p->depth > 0 && !getenv("APT_OLD_QUEUE")) {
+        // 8-sphere scene with compaction: one wave per workgroup, a stream of `ppw` pixels per wave (pt_queue.h)
+        QueueArgs qa;
+        const uint32_t unit_items = 4u * lp.maxleaf;
+        qa.nbuf = std::max(2u, std::min(16u, (512u + unit_items - 1u) / unit_items));
+        qa.buf_bytes = unit_items * 12u;
+        uint64_t ppw = pixel_count / 32768u;                     // >= 8 rounds of waves on 256 CUs x 16 waves
+        ppw = std::max<uint64_t>(2, std::min<uint64_t>(16, ppw));
+        if (const char *env = getenv("APT_QUEUE_PPW")) { const long v = atol(env); if (v >= 1 && v <= 4096) ppw = (uint64_t)v; }
+        qa.ppw = (uint32_t)ppw;
+        const uint64_t waves = (pixel_count + ppw - 1) / ppw;
+        if (waves > 0x7fffffffull) return fail(APT_ERR_ARG, "pixel_count too large for one launch; shard it%s");
+        if (const char *env = getenv("APT_QUEUE_NBUF")) { const long v = atol(env); if (v >= 2 && v <= 16) qa.nbuf = (uint32_t)v; }   // experiments only
+        size_t qlds = queue_lds_bytes(ta.rr_start != 0, qa.nbuf, lp.nleaves > 1, qa.buf_bytes);
+        if (const char *env = getenv("APT_QUEUE_LDS_PAD")) { const long v = atol(env); if (v > 0 && v <= 32768) qlds += (size_t)v; }  // experiments only: lowers the occupancy
+        if (p->mode == APT_MODE_ORACLE) hipLaunchKernelGGL((render_frame_queue8_kernel<kModeOracle>), dim3((unsigned)waves), dim3(64), qlds, st, spheres, fa, ta, lp, qa);
+        else hipLaunchKernelGGL((render_frame_queue8_kernel<kModeKernel>), dim3((unsigned)waves), dim3(64), qlds, st, spheres, fa, ta, lp, qa);
+        hipError_t e = hipGetLastError();
+        return e == hipSuccess ? APT_OK : hip_fail(e);
+    }
     size_t lds = lp.nleaves > 1 ? (size_t)kMaxStack * 3 * kStackSlots * sizeof(float) : 0;
     if (retire && (ns8 || !ta.grid) && group == 8) lds += (size_t)(kBlock / 64) * 3 * 8 * lp.maxleaf * sizeof(float); // colour queue
     const dim3 grid((unsigned)blocks);
