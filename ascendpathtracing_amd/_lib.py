@@ -92,6 +92,23 @@ def lib():
     return _lib
 
 
+def build_id():
+    """Identifies the build of the library by its SOURCES (sha256 over ascendpathtracing_amd/csrc/*.{h,hip,cpp}, the Makefile and the
+    public header, first 16 hex digits): what profiles/summarize.py stamps the recorded PMC traffic with and bench.py compares
+    before it reports that traffic for the library it is running."""
+    import glob
+    import hashlib
+    csrc = os.path.join(_HERE, "csrc")
+    files = sorted(glob.glob(os.path.join(csrc, "*.h")) + glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.cpp")))
+    files += [os.path.join(csrc, "Makefile"), os.path.join(os.path.dirname(_HERE), "include", "render_mi355x.h")]
+    h = hashlib.sha256()
+    for f in files:
+        h.update(os.path.basename(f).encode() + b"\0")
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def check(rc, what):
     if rc != APT_OK:
         raise AptError(f"{what} failed ({rc}): {lib().apt_last_error().decode()}")

@@ -14,8 +14,9 @@
 //   * after every bounce the lanes whose path is finished (alive bit cleared, throughput zero, depth reached: wave
 //     masks on the scalar unit) park their throughput in the unit's colour buffer in LDS and take the next pool
 //     entries: ballot -> mbcnt rank -> one exec-masked block of ds_reads straight into the path-state registers;
-//     9 VALU instructions per bounce for the whole refill, none for parking;
-//   * a unit whose items have all been parked (one LDS counter per colour buffer, bumped by the parking lanes) is
+//     3 VALU instructions per bounce to detect finished paths, 7 for the whole refill, none for parking;
+//   * a unit whose items have all been parked (all of them handed out -- the pool is a FIFO, so that is a count -- and
+//     no running lane's colour address inside the unit's buffer: evaluated only when the generator needs the buffer) is
 //     summed exactly as numpy's pairwise np.mean does it -- lane (sub, j) adds samples j, 8+j, ... in order, 3-step
 //     butterfly, the n % 8 tail in order, leaves combined through a stack -- by the lanes of the wave, then
 //     decoded (data_visualization.py:36-57).  Colour buffers form a ring of `nbuf` units, so tracing unit u+1 overlaps
@@ -44,16 +45,18 @@ constexpr uint32_t kPoolBatch = 64;      // rays generated at a time: one per la
 struct QueueArgs {
     uint32_t ppw;        // pixels per wave
     uint32_t nbuf;       // colour buffers = units that may be in flight (>= 2)
-    uint32_t buf_bytes;  // bytes per colour buffer: 4 * maxleaf * 12
+    uint32_t buf_bytes;  // bytes per colour buffer: queue_buf_bytes(maxleaf)
 };
+// A colour buffer holds the 4 * n items of a unit as [sub-pixel][sample][3] floats, every sub-pixel's block shifted by 4 more
+// bytes (a block of n * 12 bytes is a multiple of 256 bytes for n = 64: the four chains of a lane group would hit the same banks).
+__host__ __device__ inline uint32_t queue_buf_bytes(uint32_t maxleaf) { return 4u * maxleaf * 12u + 16u; }
 // LDS of render_frame_queue8_kernel (all of it dynamic, so that the ray pool sits at LDS address 0 and a pool entry's address
-// needs no base added), in bytes from its start: pool_a | pool_b | scene table | camera | roulette keys | counters | stack | colours
+// needs no base added), in bytes from its start: pool_a | pool_b | scene table | camera | roulette keys | stack | colours
 static_assert(kPool * 16u == 2048u, "the refill block's ds_read offsets assume pool_b at byte 2048");
 __host__ __device__ inline uint32_t queue_lds_off_tab() { return 2u * kPool * 16u; }
 __host__ __device__ inline uint32_t queue_lds_off_cam() { return queue_lds_off_tab() + (uint32_t)kTab8Floats4 * 16u; }
 __host__ __device__ inline uint32_t queue_lds_off_key() { return queue_lds_off_cam() + (uint32_t)sizeof(Camera); }
-__host__ __device__ inline uint32_t queue_lds_off_cnt(bool rr) { return queue_lds_off_key() + (rr ? kPool * 8u : 0u); }
-__host__ __device__ inline uint32_t queue_lds_off_stack(bool rr, uint32_t nbuf) { return queue_lds_off_cnt(rr) + ((nbuf * 4u + 15u) & ~15u); }
+__host__ __device__ inline uint32_t queue_lds_off_stack(bool rr, uint32_t nbuf) { (void)nbuf; return queue_lds_off_key() + (rr ? kPool * 8u : 0u); }
 __host__ __device__ inline uint32_t queue_lds_off_colq(bool rr, uint32_t nbuf, bool stack) {
     return queue_lds_off_stack(rr, nbuf) + (stack ? (uint32_t)kMaxStack * 3u * 4u * 4u : 0u);
 }
@@ -84,14 +87,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(APT_QUEUE8_W
     const uint32_t nbuf = qa.nbuf;
 
     float4 *pool_a = reinterpret_cast<float4 *>(qlds);                 // (ox, oy, dx, dy)
-    float4 *pool_b = pool_a + kPool;                                   // (oz, dz, colour address, counter address)
+    float4 *pool_b = pool_a + kPool;                                   // (oz, dz, colour address, bounce countdown)
     uint64_t *pool_key = reinterpret_cast<uint64_t *>(qlds + queue_lds_off_key());       // Russian-roulette key (APT_FLAG_RR only)
-    uint32_t *cnt = reinterpret_cast<uint32_t *>(qlds + queue_lds_off_cnt(rr));          // parked items per colour buffer
     float *stack = reinterpret_cast<float *>(qlds + queue_lds_off_stack(rr, nbuf));      // [kMaxStack][3][4] when nleaves > 1
     const uint32_t colq_off = queue_lds_off_colq(rr, nbuf, nleaves > 1);
     unsigned char *colq = qlds + colq_off;                              // [nbuf][items][3] floats
     constexpr uint32_t qlds_base = 0u;                                  // LDS byte address of the dynamic region (checked above)
-    if (lane < nbuf) cnt[lane] = 0u;
     __syncthreads();
 
     // this wave's pixels
@@ -106,7 +107,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(APT_QUEUE8_W
     uint32_t g_pi = (uint32_t)(q0 / H), g_pj = (uint32_t)(q0 % H);
     uint32_t a_unit = 0, a_leaf = 0, a_px = 0, a_buf = 0, a_sp = 0;     // accumulation cursor (units are summed in order)
     uint64_t active = 0, alive = 0;                                     // lanes with a running path / that has not hit the light
-    uint32_t iter = 0;                                                  // bounces executed by this wave so far
+    uint32_t issued = 0, a_end = 4u * lp.len(0);                        // items handed to lanes so far / the count at which the oldest unsummed unit ends
     uint32_t traced = 0, n_bounce_exec = 0, n_gen_exec = 0, n_exact = 0; // statistics
 
     // ---- per-lane path state ------------------------------------------------------------------------------------
@@ -114,8 +115,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(APT_QUEUE8_W
     path_init(s, 0.f, 0.f, 0.f, 0.f, 0.f, 1.f);
     f2 thr_xy = {1.0f, 1.0f};
     float thr_z = 1.0f;
-    uint32_t caddr = qlds_base + colq_off, cntaddr = qlds_base + queue_lds_off_cnt(rr); // LDS addresses of the item's colour / its buffer's counter
-    uint32_t stop = 0;                                                  // value of `iter` at which the path has done `depth` bounces
+    uint32_t caddr = qlds_base + colq_off;                              // LDS address of the item's colour in its unit's buffer
+    uint32_t left = 0;                                                  // bounces the path may still do after the next one
     uint64_t key = 0;                                                   // Russian-roulette key of the running path
 
     const Gain3 gain = load_gain(sph, ta);
@@ -137,8 +138,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(APT_QUEUE8_W
         const uint32_t e = (pool_head + pool_level + lane) & (kPool - 1u);
         if (on) {
             pool_a[e] = make_float4(rox, roy, rdx, rdy);
-            pool_b[e] = make_float4(roz, rdz, __uint_as_float(qlds_base + colq_off + g_buf * qa.buf_bytes + i * 12u),
-                                    __uint_as_float(qlds_base + queue_lds_off_cnt(rr) + g_buf * 4u));
+            pool_b[e] = make_float4(roz, rdz, __uint_as_float(qlds_base + colq_off + g_buf * qa.buf_bytes + i * 12u + sub * 4u), __uint_as_float(ta.depth - 1u));
             if (rr) pool_key[e] = rr_path_key(ta.seed, path);
         }
         pool_level += nb;
@@ -160,7 +160,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(APT_QUEUE8_W
         const uint32_t nl = lp.len(a_leaf), nfull = nl & ~7u, nt = nl - nfull;
         const uint32_t sub = (lane >> 3) & 3u, j = lane & 7u;          // lanes 32..63 repeat the work of lanes 0..31
         const float *col = reinterpret_cast<const float *>(colq + a_buf * qa.buf_bytes);
-        const uint32_t base = (sub * nl + j) * 3u;
+        const uint32_t base = (sub * nl + j) * 3u + sub;                // the sub-pixel's block is shifted by sub * 4 bytes
         float acc[3];
         acc[0] = col[base] * gain.r; acc[1] = col[base + 1] * gain.g; acc[2] = col[base + 2] * gain.b; // render.cpp:194-196
         for (uint32_t i8 = 8; i8 < nfull; i8 += 8) {                    // numpy's chain r[j] += a[j + 8m]
@@ -176,7 +176,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(APT_QUEUE8_W
             acc[ch] = v;
         }
         if (nt) {                                                       // res += a[i] for the n % 8 trailing samples, in order
-            const uint32_t o = (sub * nl + nfull + (j < nt ? j : 0u)) * 3u;
+            const uint32_t o = (sub * nl + nfull + (j < nt ? j : 0u)) * 3u + sub;
             const float cr = col[o] * gain.r, cg = col[o + 1] * gain.g, cb = col[o + 2] * gain.b;
             for (uint32_t t = 0; t < nt; ++t) {
                 const int src = (int)((lane & ~7u) + t);
@@ -220,37 +220,41 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(APT_QUEUE8_W
             }
             a_sp = 0;
         }
-        if (lane == 0) cnt[a_buf] = 0u;
         ++a_unit;
         if (++a_buf == nbuf) a_buf = 0;
         if (++a_leaf == nleaves) { a_leaf = 0; ++a_px; }
+        a_end += 4u * lp.len(a_leaf);                                   // (past the wave's last unit the value is never used)
         __syncthreads();
     };
-    auto oldest_unit_parked = [&]() __attribute__((always_inline)) -> bool { // uniform LDS read; a_unit < g_unit (the unit has been generated completely)
-        const uint32_t c = (uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&cnt[a_buf], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
-        return c == 4u * lp.len(a_leaf);
+    // Are all items of the oldest unsummed unit parked?  They are when every one of them has been handed to a lane (the pool is a
+    // FIFO, so that is a count) and no running lane still holds one (its colour address lies in the unit's buffer).  Evaluated
+    // only when the generator needs the buffer or at the end -- a few times per unit -- so parking itself needs no counter
+    // (the first form of this kernel bumped an LDS counter per parking lane: same address, so serialised, every bounce).
+    auto oldest_unit_parked = [&]() __attribute__((always_inline)) -> bool {
+        if (issued < a_end) return false;
+        return (active & __builtin_amdgcn_ballot_w64(caddr - (colq_off + a_buf * qa.buf_bytes) < qa.buf_bytes)) == 0;
     };
 
     // ---- after a bounce: finished paths park their throughput (the colour is throughput * gain, applied when summed) ----
     auto park = [&]() __attribute__((always_inline)) {
-        const uint32_t orbits = f32_bits(thr_xy.x) | f32_bits(thr_xy.y) | f32_bits(thr_z);   // all three +-0 <=> the OR is +-0
-        const uint64_t zero = __builtin_amdgcn_ballot_w64(bits_f32(orbits) == 0.0f);
-        const uint64_t at_depth = __builtin_amdgcn_ballot_w64(stop == iter);
-        uint64_t done = active & (~alive | zero | at_depth);
-        {   // executed even when no lane is done (exec = 0 then: nothing happens), which keeps the control flow of the hot loop flat
-            uint64_t saved;
-            const uint32_t one = 1u;
-            asm volatile("s_and_saveexec_b64 %[sv], %[m]\n\t"
-                         "ds_write_b32 %[ca], %[rx]\n\t"
-                         "ds_write_b32 %[ca], %[ry] offset:4\n\t"
-                         "ds_write_b32 %[ca], %[rz] offset:8\n\t"
-                         "ds_add_u32 %[cn], %[one]\n\t"
-                         "s_mov_b64 exec, %[sv]"
-                         : [sv] "=&s"(saved)
-                         : [m] "s"(done), [ca] "v"(caddr), [rx] "v"(thr_xy.x), [ry] "v"(thr_xy.y), [rz] "v"(thr_z), [cn] "v"(cntaddr), [one] "v"(one)
-                         : "scc", "memory");
-            active &= ~done;
-        }
+        uint64_t zero, at_depth, saved;
+        uint32_t orbits;
+        // throughput (0,0,0): the OR of the three bit patterns is +-0 (all of them are): one v_or3, one float compare
+        asm("v_or3_b32 %0, %1, %2, %3" : "=v"(orbits) : "v"(thr_xy.x), "v"(thr_xy.y), "v"(thr_z));
+        asm("v_cmp_eq_f32_e64 %0, 0, %1" : "=s"(zero) : "v"(orbits));
+        // countdown: the borrow is the mask of the lanes that have just done their last bounce
+        asm("v_sub_co_u32_e64 %0, %1, %0, 1" : "+v"(left), "=s"(at_depth));
+        const uint64_t done = active & (~alive | zero | at_depth);
+        // executed even when no lane is done (exec = 0 then: nothing happens), which keeps the control flow of the hot loop flat
+        asm volatile("s_and_saveexec_b64 %[sv], %[m]\n\t"
+                     "ds_write_b32 %[ca], %[rx]\n\t"
+                     "ds_write_b32 %[ca], %[ry] offset:4\n\t"
+                     "ds_write_b32 %[ca], %[rz] offset:8\n\t"
+                     "s_mov_b64 exec, %[sv]"
+                     : [sv] "=&s"(saved)
+                     : [m] "s"(done), [ca] "v"(caddr), [rx] "v"(thr_xy.x), [ry] "v"(thr_xy.y), [rz] "v"(thr_z)
+                     : "scc", "memory");
+        active &= ~done;
     };
     // ---- idle lanes take the next pool entries, in pool order, straight into the state registers `st` --------------------
     auto refill = [&](PathState &st) __attribute__((always_inline)) {
@@ -258,8 +262,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(APT_QUEUE8_W
         {   // no branch around this either: with nothing wanted or an empty pool `take` is 0
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(want >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)want, 0u));
             const uint64_t take = want & __builtin_amdgcn_ballot_w64(rank < pool_level);
-            const uint32_t ea = qlds_base + (((pool_head + rank) << 4) & ((kPool - 1u) << 4));
-            const uint32_t new_stop = iter + ta.depth;
+            uint32_t ea;   // ((head + rank) * 16) mod 2048: one v_lshl_add_u32 with the scalar head * 16, one v_and
+            asm("v_lshl_add_u32 %0, %1, 4, %2" : "=v"(ea) : "v"(rank), "s"(pool_head << 4));
+            ea &= (kPool - 1u) << 4;
             uint64_t saved;
             asm volatile("s_and_saveexec_b64 %[sv], %[m]\n\t"
                          "ds_read_b64 %[oxy], %[ea]\n\t"
@@ -267,23 +272,22 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(APT_QUEUE8_W
                          "ds_read_b32 %[oz], %[ea] offset:2048\n\t"
                          "ds_read_b32 %[dz], %[ea] offset:2052\n\t"
                          "ds_read_b32 %[ca], %[ea] offset:2056\n\t"
-                         "ds_read_b32 %[cn], %[ea] offset:2060\n\t"
+                         "ds_read_b32 %[lf], %[ea] offset:2060\n\t"
                          "v_pk_add_f32 %[rxy], 1.0, 0 op_sel_hi:[0,0]\n\t"
                          "v_mov_b32 %[rz], 1.0\n\t"
-                         "v_mov_b32 %[st], %[ns]\n\t"
                          "s_waitcnt lgkmcnt(0)\n\t"
                          "s_mov_b64 exec, %[sv]"
                          : [sv] "=&s"(saved), [oxy] "+v"(st.oxy), [dxy] "+v"(st.dxy), [oz] "+v"(st.oz), [dz] "+v"(st.dz), [ca] "+v"(caddr),
-                           [cn] "+v"(cntaddr), [rxy] "+v"(thr_xy), [rz] "+v"(thr_z), [st] "+v"(stop)
-                         : [m] "s"(take), [ea] "v"(ea), [ns] "s"(new_stop)
+                           [lf] "+v"(left), [rxy] "+v"(thr_xy), [rz] "+v"(thr_z)
+                         : [m] "s"(take), [ea] "v"(ea)
                          : "scc", "memory");
             if (rr) {
-                const uint32_t e = ((pool_head + rank) & (kPool - 1u));
-                if (select_const(take, 1) != 0) key = pool_key[e];
+                if (select_const(take, 1) != 0) key = pool_key[ea >> 4];
             }
             const uint32_t nt = min((uint32_t)__popcll(want), pool_level);
             pool_head = (pool_head + nt) & (kPool - 1u);
             pool_level -= nt;
+            issued += nt;
             active |= take;
             alive |= take;
         }
@@ -292,8 +296,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(APT_QUEUE8_W
     auto post_bounce = [&]() __attribute__((always_inline)) {
         ++n_bounce_exec;
         traced += (uint32_t)__popcll(active);
-        if (rr) {   // roulette after shading bounce d (0-based) when d + 1 >= rr_start; d = iter - (stop - depth)
-            const uint32_t d = iter - (stop - ta.depth);
+        if (rr) {   // roulette after shading bounce d (0-based) when d + 1 >= rr_start; the countdown started at depth - 1
+            const uint32_t d = ta.depth - 1u - left;
             const bool on = select_const(active, 1) != 0 && d + 1u >= ta.rr_start;
             if (on) {
                 PathState t;
@@ -302,7 +306,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(APT_QUEUE8_W
                 thr_xy = t.rxy; thr_z = t.rz;
             }
         }
-        ++iter;
     };
     // One bounce of the wave, in place.  Idle lanes compute on stale state: whatever they hold is overwritten when they take
     // their next ray.  When a lane whose path can still reach an output leaves the validity range of the fast sequences
@@ -342,7 +345,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(APT_QUEUE8_W
     // unit can be summed and its buffer reused: generation is never blocked in that state.)
     auto service_full = [&](PathState &st) __attribute__((always_inline)) -> bool {
         park();
-        if (pool_level <= kPool - kPoolBatch && g_unit < U) {
+        if (__builtin_expect(pool_level <= kPool - kPoolBatch && g_unit < U, 0)) {   // (unlikely: what only this path keeps in SGPRs is what should spill)
             bool room = g_off != 0 || g_unit - a_unit < nbuf;           // a unit needs a free colour buffer to start
             if (!room && oldest_unit_parked()) { accumulate_unit(); room = true; }
             if (room) gen_batch();
@@ -353,7 +356,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(APT_QUEUE8_W
     // The hot loop: two bounces per turn, ray-generate / unit sums only in the first service.
     // `guard`: an upper bound of the loop turns a wave can need (every turn either bounces an active lane or issues rays),
     // so that a logic error can never leave a wave spinning on the GPU.
-    uint32_t guard = (uint32_t)min(2ull * ((uint64_t)npx * 4u * S * ((uint64_t)ta.depth + 1u) + 64u), 0xffffffffull);
+    uint32_t guard = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)min(2ull * ((uint64_t)npx * 4u * S * ((uint64_t)ta.depth + 1u) + 64u), 0xffffffffull));
     auto run = [&](auto planes_tag) __attribute__((always_inline)) {
         for (;;) {
             if (service_full(s) || guard-- == 0u) break;

@@ -173,7 +173,7 @@ int do_render_frame(const apt_context::Values &cv, const apt_render_params *p, v
         QueueArgs qa;
         const uint32_t unit_items = 4u * lp.maxleaf;
         qa.nbuf = std::max(2u, std::min(16u, (512u + unit_items - 1u) / unit_items));
-        qa.buf_bytes = unit_items * 12u;
+        qa.buf_bytes = queue_buf_bytes(lp.maxleaf);
         uint64_t ppw = pixel_count / 32768u;                     // >= 8 rounds of waves on 256 CUs x 16 waves
         ppw = std::max<uint64_t>(2, std::min<uint64_t>(16, ppw));
         if (const char *env = getenv("APT_QUEUE_PPW")) { const long v = atol(env); if (v >= 1 && v <= 4096) ppw = (uint64_t)v; }

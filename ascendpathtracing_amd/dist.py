@@ -106,14 +106,18 @@ class FrameShard:
                 full_fb[:, b:b + c] = fb
                 full_u8[b:b + c] = u8
 
-    def gather(self, slot=0, full_fb=None, full_u8=None, dst=0):
-        """ONE collective: every rank's packed buffer to `dst`, which scatters the stripes into the full
-        framebuffer.  Without a process group (single process) it is a local copy; with one -- even of a
+    def pixel_counts(self):
+        """Pixels every rank of the group renders (all ranks know the whole split)."""
+        return [sum(c for _, c in stripe_ranges(self.npix, r, self.world, self.stripes)) for r in range(self.world)]
+
+    def gather(self, slot=0, full_fb=None, full_u8=None):
+        """ONE collective: every rank's packed buffer to rank 0 (the only root this class supports: the receive lists are
+        allocated there), which scatters the stripes into the full framebuffer.  Without a process group (single process) it is a local copy; with one -- even of a
         single rank -- it goes through torch.distributed (RCCL on GPUs).  Blocking form of gather_async."""
-        self.gather_async(slot, full_fb, full_u8, dst)
+        self.gather_async(slot, full_fb, full_u8)
         self.finish()
 
-    def gather_async(self, slot, full_fb=None, full_u8=None, dst=0):
+    def gather_async(self, slot, full_fb=None, full_u8=None):
         """Enqueue the gather of slot `slot` (asynchronously: the collective runs on the backend's own
         stream after the work already queued on the current stream) and finish the previous one.  Shards may be
         unequal: every rank's buffer has the same padded size."""
@@ -121,10 +125,10 @@ class FrameShard:
         if self.world == 1 and not dist.is_initialized():
             self._pending = ("local", slot, full_fb, full_u8)
             return
-        if self.rank == dst:
-            work = dist.gather(self._bufs[slot], self._lists[slot], dst=dst, async_op=True)
+        if self.rank == 0:
+            work = dist.gather(self._bufs[slot], self._lists[slot], dst=0, async_op=True)
         else:
-            work = dist.gather(self._bufs[slot], None, dst=dst, async_op=True)
+            work = dist.gather(self._bufs[slot], None, dst=0, async_op=True)
         self._pending = (work, slot, full_fb, full_u8)
 
     def finish(self):
@@ -168,10 +172,16 @@ def recorded_traffic(root):
     """HBM bytes per launch of the headline kernel from the committed PMC profile (profiles/hbm_traffic.json,
     written from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes by profiles/summarize.py) together
     with the build tag it was recorded for -> (bytes or None, tag or None).  bench.py cannot collect PMC counters
-    on itself (rocprofv3 has to wrap the process)."""
+    on itself (rocprofv3 has to wrap the process), so the file carries the id of the build it was recorded on
+    (_lib.build_id(): a hash of the library's sources) and the figure is only reported for that very build:
+    any other build gets (None, "recorded for build <id>, running <id>")."""
+    from . import _lib
     path = os.path.join(root, "profiles", "hbm_traffic.json")
     if not os.path.exists(path):
         return None, None
     with open(path) as f:
         d = json.load(f)
+    have, want = d.get("build_id"), _lib.build_id()
+    if have != want:
+        return None, f"profiles/hbm_traffic.json was recorded for build {have}, this is build {want}"
     return d.get("hbm_bytes_per_launch"), d.get("tag")

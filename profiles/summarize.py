@@ -45,7 +45,9 @@ if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
     # rocprofv3 reports KiB; gfx950: FETCH_SIZE reads half of the bytes actually fetched (guide, HBM section)
     fetch = pmc["FETCH_SIZE"]["avg"] * 1024 * 2
     write = pmc["WRITE_SIZE"]["avg"] * 1024
-    json.dump({"tag": tag, "kernel": main["Name"], "hbm_gbps": (fetch + write) / out["avg_ns"],
+    sys.path.insert(0, os.path.dirname(here))
+    from ascendpathtracing_amd._lib import build_id
+    json.dump({"tag": tag, "build_id": build_id(), "kernel": main["Name"], "hbm_gbps": (fetch + write) / out["avg_ns"],
                "hbm_frac_of_8TBps": (fetch + write) / out["avg_ns"] / 8000.0,
                "fetch_bytes_per_launch_corrected_x2": fetch,
                "write_bytes_per_launch": write, "hbm_bytes_per_launch": fetch + write,

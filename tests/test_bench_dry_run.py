@@ -39,6 +39,21 @@ def test_single_process_dry_run_and_world_mismatch():
     assert r.returncode == 0, r.stderr[-1000:]
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
     assert out["n_gpus"] == 1 and out["scaling"] == "weak"
+    # launched by something that set WORLD_SIZE to another value than --gpus: refused, not silently run with the wrong world
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dry-run", "--gpus", "4"], capture_output=True, text=True,
-                       timeout=300, cwd=ROOT)
+                       timeout=300, cwd=ROOT, env=dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"))
     assert r.returncode != 0 and "nproc-per-node 4" in (r.stderr + r.stdout)
+
+
+@pytest.mark.parametrize("n", [2, 3])
+def test_plain_bench_gpus_n_launches_its_own_ranks(n):
+    """`python bench.py --gpus N` as typed (VERDICT r2 missing 2): no torchrun around it, WORLD_SIZE unset -> bench.py starts
+    `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a child process and relays rank 0's one JSON line."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "2", "--warmup", "1", "--dry-run"],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT, env=dict(env, OMP_NUM_THREADS="1"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["dry_run"] is True and out["n_gpus"] == n and out["gathered_frame_complete"] is True and out["scaling"] == "strong"

@@ -18,3 +18,18 @@ def test_no_trans_result_is_read_by_the_next_valu_instruction():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "profiles", "check_hazards.py"), os.path.join(csrc, "render_kernels.s")],
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-2000:]
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"), reason="needs hipcc")
+def test_sample_queue_kernel_has_no_static_lds():
+    """render_frame_queue8_kernel (pt_queue.h) addresses its ray pool from LDS address 0: its exec-masked refill block uses
+    immediate ds_read offsets, which is only right while the kernel has NO static LDS in front of its dynamic region."""
+    import re
+    csrc = os.path.join(ROOT, "ascendpathtracing_amd", "csrc")
+    subprocess.run(["make", "-s", "-C", csrc, "asm"], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    text = open(os.path.join(csrc, "render_kernels.s")).read()
+    found = 0
+    for m in re.finditer(r"\.amdhsa_kernel (\S*render_frame_queue8_kernel\S*)\n(.*?)\.end_amdhsa_kernel", text, re.S):
+        found += 1
+        assert re.search(r"\.amdhsa_group_segment_fixed_size 0\b", m.group(2)), m.group(1)
+    assert found >= 2
