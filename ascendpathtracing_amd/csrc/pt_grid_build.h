@@ -6,8 +6,8 @@
 //   1  radii + exact median by radix select on the float bit patterns (4 passes of 8 bits, one workgroup)
 //   2  small / large classification, ordered lists by a scan, bounding box of the small spheres   -> 40-byte read-back
 //   3  cell counts (atomics), exclusive scan over the cells                                          -> 4-byte read-back
-//   4  items scattered through per-cell cursors, every cell's list sorted (ascending sphere index, as the host's),
-//      geometry tables
+//   4  items scattered through per-cell cursors, every cell's list sorted (ascending sphere index, as the host's: short
+//      lists on the device, lists longer than 32 items on the host), geometry tables
 // Synchronous on `stream` (two small read-backs size the buffer); a build step, not a render call.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -186,11 +186,19 @@ __global__ __launch_bounds__(256) void grid_fill_kernel(GridHeader h, const floa
         items[cell_start[c] + atomicAdd(&cursor[c], 1u)] = k;
     }
 }
-// ascending sphere index inside every cell (the host fills in that order); lists are a few entries long
-__global__ __launch_bounds__(256) void grid_sort_cells_kernel(uint32_t ncells, const uint32_t *__restrict__ cell_start, uint32_t *__restrict__ items) {
+// Ascending sphere index inside every cell (the host fills in that order).  Lists are normally a few entries long and are
+// sorted here, one thread per cell; a cell with more than kGridSortInline items (clustered or coincident spheres: 1e5 spheres
+// in one spot make lists of 1e5) is only REPORTED -- (begin, end) appended to `long_cells` -- and sorted by the host
+// afterwards (apt_build_grid_device: one copy of the item array out and back, std::sort per reported cell): a single-thread
+// insertion sort over such a list would be 1e10 dependent global accesses, i.e. a hung GPU.  At most nitems / (kGridSortInline + 1)
+// cells can be long, which sizes the list.
+constexpr uint32_t kGridSortInline = 32;
+__global__ __launch_bounds__(256) void grid_sort_cells_kernel(uint32_t ncells, const uint32_t *__restrict__ cell_start, uint32_t *__restrict__ items,
+                                                              uint32_t *__restrict__ long_count, uint2 *__restrict__ long_cells) {
     const uint32_t c = blockIdx.x * 256 + threadIdx.x;
     if (c >= ncells) return;
     const uint32_t b = cell_start[c], e = cell_start[c + 1];
+    if (e - b > kGridSortInline) { long_cells[atomicAdd(long_count, 1u)] = make_uint2(b, e); return; }
     for (uint32_t i = b + 1; i < e; ++i) {
         const uint32_t v = items[i];
         uint32_t j = i;

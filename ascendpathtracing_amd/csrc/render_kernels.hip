@@ -329,6 +329,9 @@ int apt_render_host(uint32_t blockDim, const uint8_t *rays, const uint8_t *spher
     if (!rays || !spheres || !colors) return fail(APT_ERR_ARG, "rays/spheres/colors must be non-null%s");
     const apt_context::Values cv = apt::default_context().snapshot();
     const apt_render_params &p = cv.params;
+    // The reference's call renders the whole ray array (src/main.cpp:18-25); with a path sub-range in the default parameters the
+    // colours outside it would be copied back from memory no kernel wrote.
+    if (p.path_begin != 0 || p.path_count != 0) return fail(APT_ERR_ARG, "apt_render_host: the default parameters carry a path sub-range; it renders whole frames only%s");
     const size_t n = (size_t)p.width * p.height * 4u * p.samples;
     const size_t sph_bytes = ((size_t)p.num_spheres * 10 + 127) / 128 * 128 * sizeof(float);
     float *d_rays = nullptr, *d_sph = nullptr, *d_col = nullptr;
@@ -424,7 +427,10 @@ int apt_multi_render(apt_multi *m, float *fb_root, uint8_t *u8_root, float *band
             split_range(npix, (uint64_t)s * nb + b, parts, begin, count);   // interleaved: stripe s*nb + b belongs to band b
             float *fb = bd.fb + (size_t)s * 3 * m->max_stripe;
             uint8_t *u8 = bd.u8 + (size_t)s * 3 * m->max_stripe;
-            rc = do_render_frame(cv, &m->params, bd.stream, bd.sph, begin, count, fb, u8_root ? u8 : nullptr);
+            // the statistics block of the default context is an address on ITS device: only bands on the root device may count into it
+            apt_context::Values cvb = cv;
+            if (bd.device != m->root) cvb.trace_counter = nullptr;
+            rc = do_render_frame(cvb, &m->params, bd.stream, bd.sph, begin, count, fb, u8_root ? u8 : nullptr);
             if (rc != APT_OK) break;
             if (s + 1 == m->stripes) e = hipEventRecord(bd.stop, bd.stream);  // kernels only: the copies follow
         }
@@ -460,7 +466,9 @@ int apt_build_grid_device(const float *spheres_dev, uint32_t ns, void *stream, v
     hipStream_t st = (hipStream_t)stream;
     // workspace: radii, the two ordered lists, statistics (freed on return; a build step, not a render call)
     float *rad = nullptr;
-    uint32_t *large = nullptr, *small = nullptr, *count = nullptr, *cursor = nullptr, *sums = nullptr;
+    uint32_t *large = nullptr, *small = nullptr, *count = nullptr, *cursor = nullptr, *sums = nullptr, *long_count = nullptr;
+    uint2 *long_cells = nullptr;
+    bool break_out = false;
     GridBuildStats *stats_d = nullptr;
     hipError_t e = hipMalloc(&rad, (size_t)ns * 4);
     if (e == hipSuccess) e = hipMalloc(&large, (size_t)ns * 4);
@@ -507,18 +515,40 @@ int apt_build_grid_device(const float *spheres_dev, uint32_t ns, void *stream, v
                 if (e == hipSuccess) e = hipMemcpyAsync(w + h.off_cells, count, nc1 * 4, hipMemcpyDeviceToDevice, st);
                 if (e == hipSuccess) {
                     if (stt.nsmall) hipLaunchKernelGGL(grid_fill_kernel, dim3((stt.nsmall + 255) / 256), dim3(256), 0, st, h, spheres_dev, rad, small, stt.nsmall, count, cursor, w + h.off_items);
-                    hipLaunchKernelGGL(grid_sort_cells_kernel, dim3((h.ncells + 255) / 256), dim3(256), 0, st, h.ncells, count, w + h.off_items);
+                    // short cell lists are sorted on the device, long ones (clustered scenes) reported and sorted here
+                    const uint32_t max_long = nitems / (kGridSortInline + 1u) + 1u;
+                    e = hipMalloc(&long_cells, (size_t)max_long * sizeof(uint2));
+                    if (e == hipSuccess) e = hipMalloc(&long_count, 4);
+                    if (e == hipSuccess) e = hipMemsetAsync(long_count, 0, 4, st);
+                    uint32_t nlong = 0;
+                    if (e == hipSuccess) {
+                        hipLaunchKernelGGL(grid_sort_cells_kernel, dim3((h.ncells + 255) / 256), dim3(256), 0, st, h.ncells, count, w + h.off_items, long_count, long_cells);
+                        e = hipMemcpyAsync(&nlong, long_count, 4, hipMemcpyDeviceToHost, st);
+                        if (e == hipSuccess) e = hipStreamSynchronize(st);
+                    }
+                    if (e == hipSuccess && nlong) {
+                        std::vector<uint2> cells(nlong);
+                        std::vector<uint32_t> host_items(nitems);
+                        e = hipMemcpy(cells.data(), long_cells, (size_t)nlong * sizeof(uint2), hipMemcpyDeviceToHost);
+                        if (e == hipSuccess) e = hipMemcpy(host_items.data(), w + h.off_items, (size_t)nitems * 4, hipMemcpyDeviceToHost);
+                        if (e == hipSuccess) {
+                            for (const uint2 &c : cells) std::sort(host_items.begin() + c.x, host_items.begin() + c.y);
+                            // only the long cells go back: the short ones were sorted in place by the kernel above (the copy out saw them sorted already)
+                            e = hipMemcpy(w + h.off_items, host_items.data(), (size_t)nitems * 4, hipMemcpyHostToDevice);
+                        }
+                    }
+                    if (e != hipSuccess) break_out = true;
                     const uint32_t ng = ns > nitems ? ns : nitems;
-                    hipLaunchKernelGGL(grid_geom_kernel, dim3((ng + 255) / 256), dim3(256), 0, st, spheres_dev, ns, w + h.off_items, nitems,
+                    if (!break_out) hipLaunchKernelGGL(grid_geom_kernel, dim3((ng + 255) / 256), dim3(256), 0, st, spheres_dev, ns, w + h.off_items, nitems,
                                        reinterpret_cast<float4 *>(w + h.off_geom), reinterpret_cast<float4 *>(w + h.off_item_geom));
-                    e = hipGetLastError();
+                    if (e == hipSuccess) e = hipGetLastError();
                     if (e == hipSuccess) e = hipStreamSynchronize(st);       // the workspace is freed below
                 }
             }
         }
     }
     (void)hipFree(rad); (void)hipFree(large); (void)hipFree(small); (void)hipFree(stats_d);
-    (void)hipFree(count); (void)hipFree(cursor); (void)hipFree(sums);
+    (void)hipFree(count); (void)hipFree(cursor); (void)hipFree(sums); (void)hipFree(long_count); (void)hipFree(long_cells);
     if (rc != APT_OK) return rc;
     return e == hipSuccess ? APT_OK : hip_fail(e);
 }

@@ -310,7 +310,11 @@ def render_reference_frame(w, h, s, depth=5, seed=0, spheres=None, mode=None, fl
     u8 = torch.empty((pixel_count, 3), dtype=torch.uint8, device="cuda")
     rays = torch.empty(6 * band_pixels * per_pixel, dtype=torch.float32, device="cuda")
     colors = torch.empty(3 * band_pixels * per_pixel, dtype=torch.float32, device="cuda")
-    st = _stream_handle(stream)
+    # Everything of a band -- the three launches, the copy of its pixels into `fb` and the wait before its buffers are reused --
+    # runs on ONE stream: torch's current stream inside the `with` below (a caller's side stream included; before round 3 the copy
+    # and the wait used the current stream while the launches used `stream`).
+    tstream = torch.cuda.current_stream() if stream is None else (torch.cuda.ExternalStream(stream) if isinstance(stream, int) else stream)
+    st = _stream_handle(tstream)
     state_blk, state = (None, None) if mt_state is None else mt_state
 
     def advance(raw, blk_from, blk_to):     # raw state of block blk_from -> raw state of block blk_to (host, sequential)
@@ -329,7 +333,9 @@ def render_reference_frame(w, h, s, depth=5, seed=0, spheres=None, mode=None, fl
         ck, nxt = gen_data.mt19937_checkpoints_window(blk0, blk1 - blk0, seed, stride, state if state_blk == blk0 else None)
         # the window's end state is the raw state of block blk1; the next band starts at block (b + c) // 156 = blk1 or blk1 - 1
         # (a band boundary inside a block), so keep the state of the LAST block of this window instead when they overlap
-        ck_d = torch.from_numpy(ck.view(np.int32)).cuda()
+        with torch.cuda.stream(tstream):                    # the upload is ordered before the launch that reads it
+            ck_d = torch.from_numpy(ck.view(np.int32)).cuda()
+            fb_band = torch.empty((3, nq), dtype=torch.float32, device="cuda")
         p = make_params(w, h, s, depth=depth, mode=mode, flags=flags | APT_FLAG_BAND_BUFFERS, path_begin=b, path_count=c)
         check(lib().apt_gen_rays_mt_device_ex(ctypes.byref(p), st, ctypes.c_void_p(ck_d.data_ptr()), ctypes.c_uint32(stride),
                                               ctypes.c_uint64(ck.shape[0]), ctypes.c_uint64(blk0), ctypes.c_void_p(rays.data_ptr())),
@@ -337,12 +343,12 @@ def render_reference_frame(w, h, s, depth=5, seed=0, spheres=None, mode=None, fl
         check(lib().render_do_ex(ctypes.byref(p), st, ctypes.c_void_p(rays.data_ptr()), _dev_f32(spheres, "spheres"),
                                  ctypes.c_void_p(colors.data_ptr())), "render_do_ex")
         o = q0 - pixel_begin
-        fb_band = torch.empty((3, nq), dtype=torch.float32, device="cuda")
         check(lib().apt_decode_color_band(ctypes.byref(p), st, ctypes.c_void_p(colors.data_ptr()), ctypes.c_uint64(nq),
                                           ctypes.c_void_p(fb_band.data_ptr()), ctypes.c_void_p(u8[o:o + nq].data_ptr())),
               "apt_decode_color_band")
-        fb[:, o:o + nq] = fb_band
-        torch.cuda.current_stream().synchronize()           # the checkpoint table of this band may now be freed / rays reused
+        with torch.cuda.stream(tstream):
+            fb[:, o:o + nq] = fb_band
+        tstream.synchronize()                               # the checkpoint table of this band may now be freed / rays reused
         state_blk, state = blk1, nxt
         if (b + c) % 156:                                    # the next band starts inside block blk1 - 1: re-derive from this window's table
             last_cp = (blk1 - 1 - blk0) // stride

@@ -140,7 +140,8 @@ int apt_set_default_params(const apt_render_params *p);
  * spheres, colors) on HOST buffers and the call is synchronous.  This entry takes the same HOST buffers
  * (24*N, 512 (padded table) and 12*N bytes for the default context's parameters), copies them to device 0's
  * current device, renders, copies the colours back and returns when they are there.  Allocates and frees its
- * device buffers; not capture-safe.  (The arithmetic still runs on the GPU: there is no CPU path.) */
+ * device buffers; not capture-safe.  Whole frames only, like the reference's call: APT_ERR_ARG when the default
+ * parameters carry a path sub-range.  (The arithmetic still runs on the GPU: there is no CPU path.) */
 int apt_render_host(uint32_t blockDim, const uint8_t *rays, const uint8_t *spheres, uint8_t *colors);
 
 /* ---- contexts: per-caller settings instead of process-wide ones ---------------------------------
