@@ -197,7 +197,7 @@ __global__ __launch_bounds__(kBlock, TWO ? APT_TWO_WAVES : (RETIRE && SC == kSce
 
     const Gain3 gain = load_gain(sph, ta);
     struct Col { float r, g, b; };
-    auto sample = [&](uint32_t k) -> Col {
+    auto sample = [&](uint32_t k) __attribute__((always_inline)) -> Col {
         double u1, u2;
         path_uniforms(fa.seed, pbase + k, u1, u2);
         float rox, roy, roz, rdx, rdy, rdz;
@@ -211,7 +211,7 @@ __global__ __launch_bounds__(kBlock, TWO ? APT_TWO_WAVES : (RETIRE && SC == kSce
     };
     auto add = [](const Col &a, const Col &b) { return Col{a.r + b.r, a.g + b.g, a.b + b.b}; };
     struct Col2 { Col a, b; };
-    auto sample2 = [&](uint32_t ka, uint32_t kb) -> Col2 { // samples ka and kb of this lane's sub-pixel, traced together
+    auto sample2 = [&](uint32_t ka, uint32_t kb) __attribute__((always_inline)) -> Col2 { // samples ka and kb of this lane's sub-pixel, traced together
         PathPair pp;
         {
             double u1, u2;

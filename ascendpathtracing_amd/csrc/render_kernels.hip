@@ -174,8 +174,9 @@ int do_render_frame(const apt_context::Values &cv, const apt_render_params *p, v
         const uint32_t unit_items = 4u * lp.maxleaf;
         qa.nbuf = std::max(2u, std::min(16u, (512u + unit_items - 1u) / unit_items));
         qa.buf_bytes = queue_buf_bytes(lp.maxleaf);
-        uint64_t ppw = pixel_count / 32768u;                     // >= 8 rounds of waves on 256 CUs x 16 waves
-        ppw = std::max<uint64_t>(2, std::min<uint64_t>(16, ppw));
+        // pixels per wave: 16 at C2 (lane efficiency 0.98; 8 / 16 / 24 measured within 0.5 % of each other, 2 costs 6 %), fewer only
+        // for frames too small to fill the chip's ~3800 wave slots a few times over
+        uint64_t ppw = std::max<uint64_t>(4, std::min<uint64_t>(16, pixel_count / 8192u));
         if (const char *env = getenv("APT_QUEUE_PPW")) { const long v = atol(env); if (v >= 1 && v <= 4096) ppw = (uint64_t)v; }
         qa.ppw = (uint32_t)ppw;
         const uint64_t waves = (pixel_count + ppw - 1) / ppw;

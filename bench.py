@@ -132,21 +132,26 @@ def quality_check(cfg, fb, u8, pixels=2048):
             "reference": "oracle C restatement, K-mode", "target_rms": 1e-4}
 
 
-def gathered_frame_check(full_fb, full_u8, case_name="C3_bands"):
+def gathered_frame_check(full_fb, full_u8, case_names=("C3_bands", "C3_spread", "C3_band5_whole")):
     """N > 1: the frame rank 0 holds after the gather against the oracle-made hashes committed under tests/golden/
-    (data, made by tests/golden/make_fullsize_hashes.py): first and last image column of each of the reference's 8 bands."""
+    (data, made by tests/golden/make_fullsize_hashes.py): first and last image column of each of the reference's 8 bands,
+    64 ranges of 1024 pixels spread over the whole frame (interior pixels of every band) and ALL 2^21 pixels of band 5."""
     import hashlib
     import numpy as np
     with open(os.path.join(ROOT, "tests", "golden", "fullsize_hashes.json")) as f:
-        case = json.load(f)["cases"][case_name]
-    bad = []
-    for k, (b, c) in enumerate(case["ranges"]):
-        fb = np.ascontiguousarray(full_fb[:, b:b + c].cpu().numpy())
-        u8 = np.ascontiguousarray(full_u8[b:b + c].cpu().numpy())
-        if hashlib.sha256(fb.tobytes()).hexdigest() != case["fb_sha256"][k] or hashlib.sha256(u8.tobytes()).hexdigest() != case["u8_sha256"][k]:
-            bad.append(k)
-    return {"checked_against": f"tests/golden/fullsize_hashes.json:{case_name} (oracle, {len(case['ranges'])} column ranges of the gathered frame)",
-            "ranges": len(case["ranges"]), "mismatching_ranges": bad, "ok": not bad}
+        cases = json.load(f)["cases"]
+    bad, n, pixels = [], 0, 0
+    for name in case_names:
+        case = cases[name]
+        for k, (b, c) in enumerate(case["ranges"]):
+            fb = np.ascontiguousarray(full_fb[:, b:b + c].cpu().numpy())
+            u8 = np.ascontiguousarray(full_u8[b:b + c].cpu().numpy())
+            if hashlib.sha256(fb.tobytes()).hexdigest() != case["fb_sha256"][k] or hashlib.sha256(u8.tobytes()).hexdigest() != case["u8_sha256"][k]:
+                bad.append(f"{name}[{k}]")
+            n += 1
+            pixels += c
+    return {"checked_against": "tests/golden/fullsize_hashes.json: " + ", ".join(case_names) + " (oracle-made hashes of ranges of the gathered frame)",
+            "ranges": n, "pixels_checked": pixels, "mismatching_ranges": bad, "ok": not bad}
 
 
 def timed(torch, fn, reps):

@@ -75,6 +75,15 @@ CASES = {
     # ... and 8 spread ranges of 256 pixels of the real 1080p / 256 spp frame
     "C4_1080p": dict(w=1920, h=1080, s=64, depth=8, mode="K", flags=0, seed=0, scene=("scene", 10000, 1),
                      ranges=spread(1920 * 1080, 8, 256)),
+    # Round 3: interior pixels of the big frames.  One WHOLE rank band of C3 (band 5 of 8: 2^21 pixels,
+    # 2.1e9 paths, in 16 chunks), 64 spread ranges of 1024 pixels over the whole C3 frame (every band's interior), and 64 more
+    # spread ranges of the C4 1080p frame.
+    "C3_band5_whole": dict(w=4096, h=4096, s=256, depth=8, mode="K", flags=0, seed=0, scene="demo",
+                           ranges=[[5 * (1 << 21) + b, c] for b, c in chunks(1 << 21, 16)]),
+    "C3_spread": dict(w=4096, h=4096, s=256, depth=8, mode="K", flags=0, seed=0, scene="demo",
+                      ranges=[[(k * 2654435761 + 12345) % (4096 * 4096 - 1024), 1024] for k in range(64)]),
+    "C4_1080p_spread": dict(w=1920, h=1080, s=64, depth=8, mode="K", flags=0, seed=0, scene=("scene", 10000, 1),
+                            ranges=[[(k * 40503 * 4099 + 977) % (1920 * 1080 - 128), 128] for k in range(64)]),
 }
 
 

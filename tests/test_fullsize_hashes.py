@@ -6,6 +6,9 @@ tests/golden/make_fullsize_hashes.py).  Always on under -m gpu: the whole file c
     C5_rr     1920x1080, 256 spp, 32 bounces, Russian roulette    whole frame (BASELINE configs[4] as named)
     C5_full   the same without roulette                           whole frame
     C3_bands  4096x4096, 1024 spp, 8 bounces                      first/last column of each of the 8 rank bands
+    C3_band5_whole / C3_spread (round 3)                          ALL 2^21 pixels of rank band 5; 64 ranges of 1024 pixels
+                                                                  spread over the whole frame (every band's interior)
+    C4_1080p_spread (round 3)                                     64 more ranges of the 10 000-sphere 1080p frame
     C4_*      10 000-sphere scene                                 a whole 480x270 frame (brute force and grid) and
                                                                   ranges of the 1080p / 256 spp frame (grid)
 The CPU test at the bottom re-runs the oracle on a few ranges so that the committed file cannot drift from it.
@@ -121,7 +124,12 @@ def test_c3_band_edges_of_all_eight_ranks(apt):
         fb, u8 = apt.render.render_frame(_params(apt, case, ns), sph, b, c)
         torch.cuda.synchronize()
         _check_ranges(case, fb, u8, b, f"C3 band {r}")
-    assert len(case["ranges"]) == 16
+        if r == 5:       # round 3: every pixel of this band (16 chunks that tile it) ...
+            whole = HASHES["C3_band5_whole"]
+            assert whole["ranges"][0][0] == b and sum(n for _, n in whole["ranges"]) == c
+            _check_ranges(whole, fb, u8, b, "C3 band 5, all pixels")
+        _check_ranges(HASHES["C3_spread"], fb, u8, b, f"C3 band {r}, spread interior ranges")   # ... and interior ranges of every band
+    assert len(case["ranges"]) == 16 and len(HASHES["C3_spread"]["ranges"]) == 64
 
 
 @pytest.mark.gpu
@@ -139,6 +147,7 @@ def test_c4_ten_thousand_spheres(apt):
     fb, u8 = apt.render.render_frame(_params(apt, case, ns, accel=grid.data_ptr()), sph)
     torch.cuda.synchronize()
     _check_ranges(case, fb, u8, 0, "C4 1080p grid")
+    _check_ranges(HASHES["C4_1080p_spread"], fb, u8, 0, "C4 1080p grid, 64 more ranges")
     for b, c in case["ranges"]:
         fb, u8 = apt.render.render_frame(_params(apt, case, ns), sph, b, c)
         torch.cuda.synchronize()
@@ -151,7 +160,7 @@ def test_committed_hashes_are_the_oracles(oracle):
     assert set(HASHES) >= {"C2", "C2_omode", "C5_rr", "C5_full", "C3_bands", "C4_crop", "C4_1080p"}
     for name, case in HASHES.items():
         assert len(case["ranges"]) == len(case["fb_sha256"]) == len(case["u8_sha256"]), name
-    for name, picks in (("C3_bands", [0, 15]), ("C2_omode", [3])):
+    for name, picks in (("C3_bands", [0, 15]), ("C2_omode", [3]), ("C3_spread", [7, 40])):
         case = HASHES[name]
         p = oracle.make_params(case["w"], case["h"], case["s"], depth=case["depth"],
                                mode=oracle.MODE_O if case["mode"] == "O" else oracle.MODE_K,
