@@ -5,6 +5,7 @@
 #include "pt_trace.h"
 #include "pt_trace2.h"
 #include "pt_queue.h"
+#include "pt_frame_mt.h"
 
 namespace {
 

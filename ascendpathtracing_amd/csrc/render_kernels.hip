@@ -645,6 +645,39 @@ int apt_gen_rays_mt_device(const apt_render_params *p, void *stream, const uint3
     return apt_gen_rays_mt_device_ex(p, stream, checkpoints, stride, num_checkpoints, 0, rays);
 }
 
+int apt_render_frame_mt(const apt_render_params *p, void *stream, const uint32_t *checkpoints, uint64_t num_checkpoints,
+                        uint64_t first_group, const float *spheres, uint64_t pixel_begin, uint64_t pixel_count, float *fb, uint8_t *fb_u8) {
+    clear_error();
+    int rc = check_params(p);
+    if (rc) return rc;
+    if (!checkpoints || !spheres || !fb) return fail(APT_ERR_ARG, "apt_render_frame_mt: checkpoints/spheres/fb must be non-null%s");
+    if (p->num_spheres != 8) return fail(APT_ERR_SCENE, "apt_render_frame_mt: the 8-sphere scene only%s");
+    if (p->flags & APT_FLAG_RR) return fail(APT_ERR_ARG, "apt_render_frame_mt: APT_FLAG_RR is not part of the reference's pipeline%s");
+    uint32_t log2_s = 0;
+    while ((1u << log2_s) < p->samples) ++log2_s;
+    if ((1u << log2_s) != p->samples || p->samples < 8 || p->samples > 256)
+        return fail(APT_ERR_ARG, "apt_render_frame_mt: samples must be 8, 16, 32, 64, 128 or 256 (other counts: the banded three-kernel pipeline)%s");
+    const uint64_t npix = (uint64_t)p->width * p->height;
+    if (pixel_begin > npix || pixel_count > npix - pixel_begin) return fail(APT_ERR_ARG, "pixel range beyond the image%s");
+    if (pixel_count == 0) return APT_OK;
+    const uint64_t g_lo = pixel_begin / kMtGroupPixels, g_hi = (pixel_begin + pixel_count + kMtGroupPixels - 1) / kMtGroupPixels;
+    if (g_lo < first_group || g_hi - first_group > num_checkpoints) return fail(APT_ERR_ARG, "apt_render_frame_mt: the checkpoint table does not cover the pixel range%s");
+    if (g_hi - g_lo > 0x7fffffffull) return fail(APT_ERR_ARG, "pixel_count too large for one launch; shard it%s");
+    const apt_context::Values cv = apt::default_context().snapshot();
+    const TraceArgs ta = make_trace_args(p, cv);
+    FrameArgs fa;
+    camera_init(fa.cam, p->width, p->height);
+    fa.width = p->width; fa.height = p->height; fa.samples = p->samples; fa.seed = p->seed;
+    fa.pixel_begin = pixel_begin; fa.pixel_count = pixel_count; fa.fb = fb; fa.fb_u8 = fb_u8;
+    MtFrameArgs ma;
+    ma.checkpoints = checkpoints + (g_lo - first_group) * 624; ma.first_group = g_lo; ma.log2_s = log2_s;
+    const dim3 grid((unsigned)(g_hi - g_lo));
+    if (p->mode == APT_MODE_ORACLE) hipLaunchKernelGGL((render_frame_mt_kernel<kModeOracle>), grid, dim3(kBlock), 0, (hipStream_t)stream, spheres, fa, ta, ma);
+    else hipLaunchKernelGGL((render_frame_mt_kernel<kModeKernel>), grid, dim3(kBlock), 0, (hipStream_t)stream, spheres, fa, ta, ma);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? APT_OK : hip_fail(e);
+}
+
 int apt_decode_color_band(const apt_render_params *p, void *stream, const float *colors, uint64_t pixel_count, float *fb,
                           uint8_t *fb_u8) {
     clear_error();

@@ -276,6 +276,59 @@ def test_scene(params: RenderParams, rays, spheres, stream=None):
     return out.view(3, -1)
 
 
+MT_GROUP_PIXELS = 78     # pixels per workgroup of the fused MT19937 frame kernel: 78 * 4 * S paths = 2 S generator blocks
+
+
+def mt_group_checkpoints(w, h, s, seed=0, pixel_begin=0, pixel_count=None, mt_state=None):
+    """Host-made generator states for render_reference_frame_fused(): -> (uint32 [groups][624], first_group).  One raw MT19937
+    state per group of 78 pixels (block g * 2 S); mt_state = (block, raw state of that block) starts a far window without walking
+    the stream from the seed."""
+    import numpy as np
+    from . import gen_data
+    npix = w * h
+    if pixel_count is None:
+        pixel_count = npix - pixel_begin
+    g_lo, g_hi = pixel_begin // MT_GROUP_PIXELS, (pixel_begin + pixel_count + MT_GROUP_PIXELS - 1) // MT_GROUP_PIXELS
+    state = None
+    if mt_state is not None:
+        blk, raw = mt_state
+        if blk > g_lo * 2 * s:
+            raise _lib.AptError("mt_state lies after the first block requested")
+        state = (np.array(raw, dtype=np.uint32) if blk == g_lo * 2 * s
+                 else gen_data.mt19937_checkpoints_window(blk, g_lo * 2 * s - blk, seed, 1 << 30, raw)[1])
+    ck, _ = gen_data.mt19937_checkpoints_window(g_lo * 2 * s, (g_hi - g_lo) * 2 * s, seed, 2 * s, state)
+    return ck, g_lo
+
+
+def render_reference_frame_fused(w, h, s, depth=5, seed=0, spheres=None, mode=None, flags=0, stream=None, pixel_begin=0,
+                                 pixel_count=None, checkpoints=None, mt_state=None):
+    """The reference's whole pipeline (np.random.seed(seed); gen_rays; test_soa arithmetic; decode_color) in ONE launch, with no
+    ray / colour buffers in HBM (apt_render_frame_mt): -> (fb float32 [3][pixel_count], fb_u8 [pixel_count][3]), not synchronised;
+    bit-identical to render_reference_frame().  s in {8, 16, ..., 256}.  checkpoints = (device int32 tensor [groups][624],
+    first_group) from mt_group_checkpoints() to reuse a table."""
+    import numpy as np
+    from . import gen_data
+    from ._lib import APT_MODE_ORACLE, make_params
+    require_gpu()
+    if spheres is None:
+        spheres = torch.from_numpy(gen_data.gen_spheres()).cuda()
+    npix = w * h
+    if pixel_count is None:
+        pixel_count = npix - pixel_begin
+    if checkpoints is None:
+        ck, g_lo = mt_group_checkpoints(w, h, s, seed, pixel_begin, pixel_count, mt_state)
+        checkpoints = (torch.from_numpy(ck.view(np.int32)).cuda(), g_lo)
+    ck_d, g_lo = checkpoints
+    p = make_params(w, h, s, depth=depth, mode=APT_MODE_ORACLE if mode is None else mode, flags=flags)
+    fb = torch.empty((3, pixel_count), dtype=torch.float32, device="cuda")
+    u8 = torch.empty((pixel_count, 3), dtype=torch.uint8, device="cuda")
+    check(lib().apt_render_frame_mt(ctypes.byref(p), _stream_handle(stream), ctypes.c_void_p(ck_d.data_ptr()), ctypes.c_uint64(ck_d.shape[0]),
+                                    ctypes.c_uint64(g_lo), _dev_f32(spheres, "spheres"), ctypes.c_uint64(pixel_begin),
+                                    ctypes.c_uint64(pixel_count), ctypes.c_void_p(fb.data_ptr()), ctypes.c_void_p(u8.data_ptr())),
+          "apt_render_frame_mt")
+    return fb, u8
+
+
 def render_reference_frame(w, h, s, depth=5, seed=0, spheres=None, mode=None, flags=0, stream=None, band_pixels=None,
                            pixel_begin=0, pixel_count=None, mt_state=None):
     """The reference's whole pipeline on the device, bit-exact with running scripts/gen_data.py

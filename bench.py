@@ -194,6 +194,21 @@ def extras(torch, apt, render, gen_data, cfg, sph, steps):
         torch.cuda.empty_cache()
     except Exception as e:                   # noqa: BLE001  (an extra must never cost the headline line)
         out["c2_exact_reference_pipeline"] = {"error": repr(e)[:200]}
+    try:                                     # (d) the same pipeline in ONE kernel (round 3): MT19937 twisted in LDS, no ray / colour buffers
+        import numpy as np
+        t0 = time.time()
+        ckg, g_lo = render.mt_group_checkpoints(W, H, S, seed=0)
+        t_ck = time.time() - t0
+        ckd = (torch.from_numpy(ckg.view(np.int32)).cuda(), g_lo)
+        ms_o = timed(torch, lambda: render.render_reference_frame_fused(W, H, S, depth=D, seed=0, spheres=sph, checkpoints=ckd), 3)
+        ms_k = timed(torch, lambda: render.render_reference_frame_fused(W, H, S, depth=D, seed=0, spheres=sph, checkpoints=ckd, mode=apt.APT_MODE_KERNEL), 3)
+        out["c2_exact_reference_pipeline_fused"] = {"total_ms": round(ms_o, 3), "k_mode_arithmetic_ms": round(ms_k, 3),
+                                                    "host_checkpoint_seconds_once": round(t_ck, 2), "hbm_gb_resident": round((ckg.nbytes + 15 * W * H) / 1e9, 3),
+                                                    "kernel": "render_frame_mt_kernel (apt_render_frame_mt): MT19937 gen_rays + render (O-mode) + decode_color"}
+        del ckd
+        torch.cuda.empty_cache()
+    except Exception as e:                   # noqa: BLE001
+        out["c2_exact_reference_pipeline_fused"] = {"error": repr(e)[:200]}
     return out
 
 

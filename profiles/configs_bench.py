@@ -99,6 +99,18 @@ report("C2 exact reference pipeline on device (MT19937 rays, buffer mode, O-mode
                             "host_checkpoint_seconds_once": round(t_ck, 2), "hbm_GB": round((9 * 4 * p.num_paths) / 1e9, 1)})
 del rays, colors, ck
 torch.cuda.empty_cache()
+# the same pipeline in one kernel (round 3: apt_render_frame_mt)
+import numpy as np
+t0 = time.time()
+ckg, g_lo = render.mt_group_checkpoints(1920, 1080, 64, seed=0)
+t_ck = time.time() - t0
+ckd = (torch.from_numpy(ckg.view(np.int32)).cuda(), g_lo)
+for mode, name in ((apt.APT_MODE_ORACLE, "O-mode"), (apt.APT_MODE_KERNEL, "K-mode")):
+    ms = timeit(lambda: render.render_reference_frame_fused(1920, 1080, 64, depth=8, seed=0, spheres=sph8, checkpoints=ckd, mode=mode), 3)
+    report(f"C2 exact reference pipeline FUSED into one kernel (MT19937 in LDS, {name})", ms, p.num_paths * 8, 8,
+           {"host_checkpoint_seconds_once": round(t_ck, 2), "hbm_GB": round((ckg.nbytes + 15 * 1920 * 1080) / 1e9, 3)})
+del ckd
+torch.cuda.empty_cache()
 # C4: 10k spheres
 scene = torch.from_numpy(gen_data.gen_scene(10000, seed=1)).cuda()
 for flags, name in ((0, ""), (apt.APT_FLAG_RETIRE, " retire")):

@@ -203,6 +203,32 @@ def test_exact_reference_pipeline_in_bands_c2_and_c3(apt):
 
 
 @pytest.mark.gpu
+def test_exact_reference_pipeline_fused_kernel_at_full_size(apt):
+    """Round 3: the fused MT19937 frame kernel (apt_render_frame_mt) on the WHOLE C2 frame against the oracle's hashes of the
+    reference's exact pipeline, and on the last image column of C3 from the committed generator state."""
+    import torch
+    cases = _mt_cases()
+    whole = cases["C2_mt_whole"]
+    w, h, s = whole["w"], whole["h"], whole["s"]
+    torch.cuda.reset_peak_memory_stats()
+    base = torch.cuda.memory_allocated()
+    fb, u8 = apt.render.render_reference_frame_fused(w, h, s, depth=whole["depth"], seed=0)
+    torch.cuda.synchronize()
+    assert torch.cuda.max_memory_allocated() - base < (1 << 28)                  # the frame and the generator states: no 19 GB of rays
+    fbh, u8h = fb.cpu().numpy(), u8.cpu().numpy()
+    bad = [k for k, (b, c) in enumerate(whole["ranges"])
+           if sha(fbh[:, b:b + c]) != whole["fb_sha256"][k] or sha(u8h[b:b + c]) != whole["u8_sha256"][k]]
+    assert not bad, bad
+    case = cases["C3_mt_last_column"]
+    f = np.load(os.path.join(ROOT, "tests", "golden", case["mt_state"]))
+    b, c = case["ranges"][0]
+    fb, u8 = apt.render.render_reference_frame_fused(case["w"], case["h"], case["s"], depth=case["depth"], seed=0, pixel_begin=b, pixel_count=c,
+                                                     mt_state=(int(f["block"]), f["state"]))
+    torch.cuda.synchronize()
+    assert sha(fb.cpu().numpy()) == case["fb_sha256"][0] and sha(u8.cpu().numpy()) == case["u8_sha256"][0]
+
+
+@pytest.mark.gpu
 def test_exact_reference_pipeline_whole_c2_banded_equals_unbanded(apt):
     """render_reference_frame at C2 in bands of 65536 pixels (0.6 GB of intermediates instead of
     19 GB) is bit-equal to the three whole-frame launches."""
