@@ -9,8 +9,8 @@
 //     pairwise leaf of one pixel = 4 sub-pixels x n <= 128 samples); nothing is drained between units, so the only
 //     idle lanes are those of the wave's very last unit;
 //   * ray-generate (float64, ~230 VALU instructions per ray) is decoupled from tracing through a per-wave LDS RAY
-//     POOL (128 entries x 32 bytes, FIFO): whenever 64 entries are free the wave generates 64 consecutive items with
-//     all 64 lanes, whatever the lanes' paths are doing;
+//     POOL (64 entries x 32 bytes, FIFO): when it is empty the wave generates 64 consecutive items with all 64 lanes,
+//     whatever the lanes' paths are doing (and serves the lanes that the pool's last entries could not serve);
 //   * after every bounce the lanes whose path is finished (alive bit cleared, throughput zero, depth reached: wave
 //     masks on the scalar unit) park their throughput in the unit's colour buffer in LDS and take the next pool
 //     entries: ballot -> mbcnt rank -> one exec-masked block of ds_reads straight into the path-state registers;
@@ -40,7 +40,10 @@ struct FrameArgs {
     uint8_t *fb_u8;  // [pixel_count][3] or null
 };
 
-constexpr uint32_t kPool = 128;          // ray pool entries per wave (power of two)
+#ifndef APT_Q8_POOL
+#define APT_Q8_POOL 64 // 64 entries (2 KB): measured against 128 in round 3 -- the LDS it frees is worth more occupancy (C5 -3 %)
+#endif
+constexpr uint32_t kPool = APT_Q8_POOL;  // ray pool entries per wave (power of two, >= kPoolBatch)
 constexpr uint32_t kPoolBatch = 64;      // rays generated at a time: one per lane
 struct QueueArgs {
     uint32_t ppw;        // pixels per wave
@@ -52,7 +55,6 @@ struct QueueArgs {
 __host__ __device__ inline uint32_t queue_buf_bytes(uint32_t maxleaf) { return 4u * maxleaf * 12u + 16u; }
 // LDS of render_frame_queue8_kernel (all of it dynamic, so that the ray pool sits at LDS address 0 and a pool entry's address
 // needs no base added), in bytes from its start: pool_a | pool_b | scene table | camera | roulette keys | stack | colours
-static_assert(kPool * 16u == 2048u, "the refill block's ds_read offsets assume pool_b at byte 2048");
 __host__ __device__ inline uint32_t queue_lds_off_tab() { return 2u * kPool * 16u; }
 __host__ __device__ inline uint32_t queue_lds_off_cam() { return queue_lds_off_tab() + (uint32_t)kTab8Floats4 * 16u; }
 __host__ __device__ inline uint32_t queue_lds_off_key() { return queue_lds_off_cam() + (uint32_t)sizeof(Camera); }
@@ -65,7 +67,7 @@ __host__ __device__ inline uint32_t queue_lds_bytes(bool rr, uint32_t nbuf, bool
 }
 
 #ifndef APT_QUEUE8_WAVES
-#define APT_QUEUE8_WAVES 4 // waves per SIMD the register budget of render_frame_queue8_kernel is set for (its LDS allows 15 waves per CU at S = 64)
+#define APT_QUEUE8_WAVES 5 // waves per SIMD the register budget of render_frame_queue8_kernel is set for (96 VGPRs; its 8.6 KB of LDS allow 18 waves per CU at S = 64)
 #endif
 template <int MODE>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(APT_QUEUE8_WAVES, APT_QUEUE8_WAVES))) void render_frame_queue8_kernel(const float *__restrict__ sph, FrameArgs fa, TraceArgs ta,
@@ -269,17 +271,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(APT_QUEUE8_W
             asm volatile("s_and_saveexec_b64 %[sv], %[m]\n\t"
                          "ds_read_b64 %[oxy], %[ea]\n\t"
                          "ds_read_b64 %[dxy], %[ea] offset:8\n\t"
-                         "ds_read_b32 %[oz], %[ea] offset:2048\n\t"
-                         "ds_read_b32 %[dz], %[ea] offset:2052\n\t"
-                         "ds_read_b32 %[ca], %[ea] offset:2056\n\t"
-                         "ds_read_b32 %[lf], %[ea] offset:2060\n\t"
+                         "ds_read_b32 %[oz], %[ea] offset:%[ob0]\n\t"
+                         "ds_read_b32 %[dz], %[ea] offset:%[ob1]\n\t"
+                         "ds_read_b32 %[ca], %[ea] offset:%[ob2]\n\t"
+                         "ds_read_b32 %[lf], %[ea] offset:%[ob3]\n\t"
                          "v_pk_add_f32 %[rxy], 1.0, 0 op_sel_hi:[0,0]\n\t"
                          "v_mov_b32 %[rz], 1.0\n\t"
                          "s_waitcnt lgkmcnt(0)\n\t"
                          "s_mov_b64 exec, %[sv]"
                          : [sv] "=&s"(saved), [oxy] "+v"(st.oxy), [dxy] "+v"(st.dxy), [oz] "+v"(st.oz), [dz] "+v"(st.dz), [ca] "+v"(caddr),
                            [lf] "+v"(left), [rxy] "+v"(thr_xy), [rz] "+v"(thr_z)
-                         : [m] "s"(take), [ea] "v"(ea)
+                         : [m] "s"(take), [ea] "v"(ea), [ob0] "n"(kPool * 16u), [ob1] "n"(kPool * 16u + 4u), [ob2] "n"(kPool * 16u + 8u), [ob3] "n"(kPool * 16u + 12u)
                          : "scc", "memory");
             if (rr) {
                 if (select_const(take, 1) != 0) key = pool_key[ea >> 4];
@@ -339,30 +341,28 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(APT_QUEUE8_W
         post_bounce();
     };
 
-    // Full service between two bounces: park, make room / generate when 64 pool entries are free, refill into `st`.
+    // Service between two bounces: park, refill from what the pool holds; when the pool has room for a batch, (sum the oldest
+    // unit if its buffer is needed,) generate 64 rays and refill again, so that a lane never idles because the pool ran dry.
     // -> true when the wave is finished: no lane got a ray although everything was offered, i.e. every unit has been
     // generated, issued and parked.  (If no lane is active and the pool is empty, every generated item is parked, so the oldest
     // unit can be summed and its buffer reused: generation is never blocked in that state.)
-    auto service_full = [&](PathState &st) __attribute__((always_inline)) -> bool {
+    auto service = [&](PathState &st) __attribute__((always_inline)) -> bool {
         park();
+        refill(st);
         if (__builtin_expect(pool_level <= kPool - kPoolBatch && g_unit < U, 0)) {   // (unlikely: what only this path keeps in SGPRs is what should spill)
             bool room = g_off != 0 || g_unit - a_unit < nbuf;           // a unit needs a free colour buffer to start
             if (!room && oldest_unit_parked()) { accumulate_unit(); room = true; }
-            if (room) gen_batch();
+            if (room) { gen_batch(); refill(st); }
         }
-        refill(st);
         return active == 0;
     };
-    // The hot loop: two bounces per turn, ray-generate / unit sums only in the first service.
+    // The hot loop: one bounce per turn, in place (no ping-pong pair: the cold exact block of step() merges into the same registers).
     // `guard`: an upper bound of the loop turns a wave can need (every turn either bounces an active lane or issues rays),
     // so that a logic error can never leave a wave spinning on the GPU.
-    uint32_t guard = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)min(2ull * ((uint64_t)npx * 4u * S * ((uint64_t)ta.depth + 1u) + 64u), 0xffffffffull));
+    uint32_t guard = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)min(4ull * ((uint64_t)npx * 4u * S * ((uint64_t)ta.depth + 1u) + 64u), 0xffffffffull));
     auto run = [&](auto planes_tag) __attribute__((always_inline)) {
         for (;;) {
-            if (service_full(s) || guard-- == 0u) break;
-            step(s, planes_tag);
-            park();                                                     // light service: no ray-generate here
-            refill(s);
+            if (service(s) || guard-- == 0u) break;
             step(s, planes_tag);
         }
     };
