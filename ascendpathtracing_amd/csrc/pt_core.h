@@ -680,10 +680,14 @@ APT_HD void russian_roulette(PathState &s, uint64_t key, uint32_t bounce) { // b
     if (s.rxy.y > q) q = s.rxy.y;
     if (s.rz > q) q = s.rz;
     if (!(q > 0.0f)) return;                    // already (0,0,0), negative or NaN: leave it
+#if defined(__HIP_DEVICE_COMPILE__)
+    const float p = __builtin_amdgcn_fmed3f(q, 0.05f, 0.95f);   // q > 0 and not NaN here: the median is clamp(q, 0.05, 0.95), one instruction
+#else
     float p = q < 0.05f ? 0.05f : q;
     p = p > 0.95f ? 0.95f : p;
+#endif
     const uint64_t h = splitmix64(key + 0x9E3779B97F4A7C15ull * (uint64_t)(bounce + 1u));
-    const float u = (float)(uint32_t)(h >> 40) * 0x1p-24f;
+    const float u = (float)((uint32_t)(h >> 32) >> 8) * 0x1p-24f;   // the 24 high bits (written on the high dword: a 32-bit conversion, not a 64-bit one)
     if (u >= p) { s.rxy.x = 0.0f; s.rxy.y = 0.0f; s.rz = 0.0f; }
     else { const float inv = 1.0f / p; s.rxy.x = s.rxy.x * inv; s.rxy.y = s.rxy.y * inv; s.rz = s.rz * inv; }
 }
