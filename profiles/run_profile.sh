@@ -4,7 +4,7 @@
 # Pass 1: --kernel-trace --stats (per-kernel durations).  Passes 2..: --pmc only, one counter
 # group per pass (never combined with tracing domains other than kernel-trace).
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 OUT=gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd "$(dirname "$0")/.." || exit 1
