@@ -171,6 +171,14 @@ def extras(torch, apt, render, gen_data, cfg, sph, steps):
     out = {}
     po = apt.make_params(W, H, S, depth=D, mode=apt.APT_MODE_ORACLE)
     out["c2_o_mode_kernel_ms"] = round(timed(torch, lambda: render.render_frame(po, sph), steps), 3)
+    # (a') the same frame of a scene WITHOUT the reference table's equality pattern of centre coordinates (spheres 0 and 6 exchanged: the
+    # mirror ball takes the left wall's slot, so cy[0..3] are no longer equal and scene8_shares_planes() fails): the general form of the
+    # intersections, 64 instead of 49 packed instructions for the 8 discriminants (how much of the headline is scene-specific)
+    perm = sph.clone().view(-1)[:80].view(10, 8).clone()
+    perm[:, [0, 6]] = perm[:, [6, 0]]
+    sph_general = sph.clone()
+    sph_general[:80] = perm.reshape(-1)
+    out["general_scene_ms"] = round(timed(torch, lambda: render.render_frame(apt.make_params(W, H, S, depth=D), sph_general), steps), 3)
     pr = apt.make_params(W, H, S, depth=D, flags=apt.APT_FLAG_RETIRE)
     rms = timed(torch, lambda: render.render_frame(pr, sph), steps)
     with render.TraceCounter() as tc:       # counted in a separate, untimed launch (the counter's atomics are slow)
