@@ -69,7 +69,9 @@ __host__ __device__ inline uint32_t queue_lds_bytes(bool rr, uint32_t nbuf, bool
 #ifndef APT_QUEUE8_WAVES
 #define APT_QUEUE8_WAVES 5 // waves per SIMD the register budget of render_frame_queue8_kernel is set for (96 VGPRs; its 8.6 KB of LDS allow 18 waves per CU at S = 64)
 #endif
-template <int MODE>
+// RR: APT_FLAG_RR (the host picks the instantiation from ta.rr_start): without it the kernel carries no roulette key and no
+// per-bounce test of the flag.
+template <int MODE, bool RR>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(APT_QUEUE8_WAVES, APT_QUEUE8_WAVES))) void render_frame_queue8_kernel(const float *__restrict__ sph, FrameArgs fa, TraceArgs ta,
                                                                  LeafProg lp, QueueArgs qa) {
     extern __shared__ __align__(16) unsigned char qlds[];
@@ -84,7 +86,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(APT_QUEUE8_W
     const Tab8 tab8 = load_scene8(sph, sc, tab); // ends with a barrier
     const KeyConsts kc = make_key_consts(ta.eps);
     const bool fast_ok = eps_allows_rootkey(ta.eps);
-    const bool rr = ta.rr_start != 0;
+    constexpr bool rr = RR;
     const uint32_t nleaves = lp.nleaves, S = fa.samples, H = fa.height;
     const uint32_t nbuf = qa.nbuf;
 

@@ -184,8 +184,14 @@ int do_render_frame(const apt_context::Values &cv, const apt_render_params *p, v
         if (const char *env = getenv("APT_QUEUE_NBUF")) { const long v = atol(env); if (v >= 2 && v <= 16) qa.nbuf = (uint32_t)v; }   // experiments only
         size_t qlds = queue_lds_bytes(ta.rr_start != 0, qa.nbuf, lp.nleaves > 1, qa.buf_bytes);
         if (const char *env = getenv("APT_QUEUE_LDS_PAD")) { const long v = atol(env); if (v > 0 && v <= 32768) qlds += (size_t)v; }  // experiments only: lowers the occupancy
-        if (p->mode == APT_MODE_ORACLE) hipLaunchKernelGGL((render_frame_queue8_kernel<kModeOracle>), dim3((unsigned)waves), dim3(64), qlds, st, spheres, fa, ta, lp, qa);
-        else hipLaunchKernelGGL((render_frame_queue8_kernel<kModeKernel>), dim3((unsigned)waves), dim3(64), qlds, st, spheres, fa, ta, lp, qa);
+        const bool rrk = ta.rr_start != 0;
+        if (p->mode == APT_MODE_ORACLE) {
+            if (rrk) hipLaunchKernelGGL((render_frame_queue8_kernel<kModeOracle, true>), dim3((unsigned)waves), dim3(64), qlds, st, spheres, fa, ta, lp, qa);
+            else hipLaunchKernelGGL((render_frame_queue8_kernel<kModeOracle, false>), dim3((unsigned)waves), dim3(64), qlds, st, spheres, fa, ta, lp, qa);
+        } else {
+            if (rrk) hipLaunchKernelGGL((render_frame_queue8_kernel<kModeKernel, true>), dim3((unsigned)waves), dim3(64), qlds, st, spheres, fa, ta, lp, qa);
+            else hipLaunchKernelGGL((render_frame_queue8_kernel<kModeKernel, false>), dim3((unsigned)waves), dim3(64), qlds, st, spheres, fa, ta, lp, qa);
+        }
         hipError_t e = hipGetLastError();
         return e == hipSuccess ? APT_OK : hip_fail(e);
     }
