@@ -280,6 +280,10 @@ int apt_build_grid_host(const float *sph, uint32_t ns, void *grid, size_t *out_b
     for (uint32_t k = 0; k < ns; ++k) { g[4 * k] = cx[k]; g[4 * k + 1] = cy[k]; g[4 * k + 2] = cz[k]; g[4 * k + 3] = r2[k]; }
     float *ig = (float *)(w + h.off_item_geom);
     for (uint32_t i = 0; i < h.nitems; ++i) memcpy(ig + 4 * (size_t)i, g + 4 * (size_t)w[h.off_items + i], 16);
+    if (h.off_cellslot) {                                                                             // pair-slot tables of the flat walk
+        for (uint32_t c = 0; c <= h.ncells; ++c) apt::grid_fill_cell_slots(w, h, c);
+        for (uint32_t k = 0; k < ns; ++k) apt::grid_fill_sphere8(w, h, sph, k);
+    }
     return APT_OK;
 }
 

@@ -602,10 +602,20 @@ APT_HD void path_uniforms(uint64_t seed, uint64_t path, double &u1, double &u2) 
 }
 
 // ---- uniform grid over the small spheres of a large scene ----------------------------------------
-// One flat buffer of 32-bit words, built on the host (host_helpers.cpp) and traversed on the device:
+// One flat buffer of 32-bit words, built on the host (host_helpers.cpp) or on the device (pt_grid_build.h), traversed on the device:
 //   GridHeader | large[nlarge] | cell_start[ncells+1] | items[nitems] | geom[Ns] float4 (cx,cy,cz,r2)
 //              | item_geom[nitems] float4 = geom[items[i]]  (cell order: the walk reads it directly, one
 //                dependent load fewer per candidate)
+//              | cellslot[ncells] | slot_geom[nslots] (8 words) | slot_ids[nslots] (2 words)  -- the PAIR-SLOT tables of the flat walk
+//              | sphere8[Ns] (8 words)
+// Pair slots (round 3; pt_trace.h grid_segment_flat): the candidates of a list, two per slot, laid out for the packed
+// two-spheres-per-instruction test and for ONE address per pair:
+//   slot_geom = (cx_a, cx_b, cy_a, cy_b | cz_a, cz_b, r2_a, r2_b), slot_ids = (id_a, id_b)      an odd list ends with a NaN sphere, id 0xffffffff
+// Slots [0, slot_base) hold the always-tested large list, then every cell's list from slot
+//   grid_slot_begin(h, cell_start[c], c) = slot_base + ((cell_start[c] + c + 1) >> 1)
+// (lists of ceil(k / 2) slots never overlap under this rule -- no second scan; the few gap slots stay zero and are never read).
+// cellslot[c] = slot_begin << 6 | min(slots of the cell, 63); 63 means "63 or more: take the count from cell_start".
+// off_cellslot == 0: the tables are absent (they would not fit 26 bits of slot index) and the walk uses item_geom.
 struct GridHeader {
     uint32_t magic, num_spheres;
     uint32_t n[3], ncells, nlarge, nitems;
@@ -613,8 +623,12 @@ struct GridHeader {
     uint32_t off_item_geom;
     float gmin[3], gmax[3], cell[3], inv_cell[3];
     float margin;                                         // how far every small sphere's box was inflated
-    uint32_t pad[2];
+    uint32_t off_cellslot, off_slots, off_slot_ids, nslots, slot_base;  // pair-slot tables (0 = absent)
+    uint32_t off_sphere8;                                 // [Ns] x 8 words (cx, cy, cz, r2, albedo r, g, b, 0): what the shading step gathers, in ONE cache line
 };
+constexpr uint32_t kGridSlotCountBits = 6;       // cellslot: low bits = slots of the cell, saturating
+constexpr uint32_t kGridSlotCountMax = (1u << kGridSlotCountBits) - 1u;
+constexpr uint32_t kGridNoSphere = 0xffffffffu;  // id of a pad
 constexpr uint32_t kGridMagic = 0x47524944u; // "GRID"
 constexpr uint32_t kGridMaxCellsPerAxis = 512;  // round 1 capped the grid at 128 cells per axis
 
@@ -650,7 +664,51 @@ inline size_t grid_header_offsets(GridHeader &h, uint32_t nitems) { // -> total 
     h.off_items = h.off_cells + h.ncells + 1;
     h.off_geom = (h.off_items + h.nitems + 3u) & ~3u;                               // 16-byte aligned float4s
     h.off_item_geom = h.off_geom + 4 * h.num_spheres;
-    return (size_t)h.off_item_geom + 4 * (size_t)h.nitems;
+    size_t words = (size_t)h.off_item_geom + 4 * (size_t)h.nitems;
+    // pair-slot tables: capacity from the placement rule (grid_slot_begin): the last list ends at or before this slot
+    h.slot_base = (h.nlarge + 1u) >> 1;
+    const uint64_t nslots = (uint64_t)h.slot_base + (((uint64_t)nitems + h.ncells + 1u) >> 1) + 1u;
+    const uint64_t off_cellslot = words, off_slots = (off_cellslot + h.ncells + 7u) & ~(uint64_t)7u;   // 32-byte aligned slots
+    const uint64_t off_ids = off_slots + nslots * 8u, off_s8 = (off_ids + nslots * 2u + 7u) & ~(uint64_t)7u, end = off_s8 + 8ull * h.num_spheres;
+    if (nslots < (1ull << (32 - kGridSlotCountBits)) && end < (1ull << 32)) {
+        h.off_cellslot = (uint32_t)off_cellslot; h.off_slots = (uint32_t)off_slots; h.off_slot_ids = (uint32_t)off_ids; h.nslots = (uint32_t)nslots;
+        h.off_sphere8 = (uint32_t)off_s8;
+        words = (size_t)end;
+    } else {
+        h.off_cellslot = h.off_slots = h.off_slot_ids = h.nslots = h.off_sphere8 = 0;
+    }
+    return words;
+}
+APT_HD uint32_t grid_slot_begin(const GridHeader &h, uint32_t cell_start_c, uint32_t c) { return h.slot_base + ((cell_start_c + c + 1u) >> 1); }
+APT_HD uint32_t grid_cellslot_entry(const GridHeader &h, uint32_t b, uint32_t e, uint32_t c) {
+    const uint32_t n = (e - b + 1u) >> 1;
+    return grid_slot_begin(h, b, c) << kGridSlotCountBits | (n < kGridSlotCountMax ? n : kGridSlotCountMax);
+}
+// The slots of one sorted id list (n ids from `ids`), starting at slot `slot`; geometry from the geom[] table already in the buffer.
+APT_HD void grid_fill_slots(uint32_t *w, const GridHeader &h, uint32_t slot, const uint32_t *ids, uint32_t n) {
+    for (uint32_t i = 0; i < n; i += 2, ++slot) {
+        uint32_t *g = w + h.off_slots + 8 * (size_t)slot, *id = w + h.off_slot_ids + 2 * (size_t)slot;
+        const uint32_t ka = ids[i], kb = i + 1 < n ? ids[i + 1] : kGridNoSphere;
+        const uint32_t *ga = w + h.off_geom + 4 * (size_t)ka;
+        g[0] = ga[0]; g[2] = ga[1]; g[4] = ga[2]; g[6] = ga[3];
+        if (kb != kGridNoSphere) { const uint32_t *gb = w + h.off_geom + 4 * (size_t)kb; g[1] = gb[0]; g[3] = gb[1]; g[5] = gb[2]; g[7] = gb[3]; }
+        else g[1] = g[3] = g[5] = g[7] = 0x7fc00000u;   // a NaN sphere: its discriminant is NaN, it can never be hit
+        id[0] = ka; id[1] = kb;
+    }
+}
+// sphere8 record of sphere k from the [10][Ns] table
+APT_HD void grid_fill_sphere8(uint32_t *w, const GridHeader &h, const float *sph, uint32_t k) {
+    const size_t ns = h.num_spheres;
+    float *r = reinterpret_cast<float *>(w + h.off_sphere8) + 8 * (size_t)k;
+    r[0] = sph[ns + k]; r[1] = sph[2 * ns + k]; r[2] = sph[3 * ns + k]; r[3] = sph[k];
+    r[4] = sph[7 * ns + k]; r[5] = sph[8 * ns + k]; r[6] = sph[9 * ns + k]; r[7] = 0.0f;
+}
+// cellslot entry and slots of cell c (c == ncells: the always-tested list); needs cell_start, items, large and geom in place
+APT_HD void grid_fill_cell_slots(uint32_t *w, const GridHeader &h, uint32_t c) {
+    if (c == h.ncells) { grid_fill_slots(w, h, 0, w + h.off_large, h.nlarge); return; }
+    const uint32_t b = w[h.off_cells + c], e = w[h.off_cells + c + 1];
+    w[h.off_cellslot + c] = grid_cellslot_entry(h, b, e, c);
+    grid_fill_slots(w, h, grid_slot_begin(h, b, c), w + h.off_items + b, e - b);
 }
 // cells [c0, c1] of axis a that the box of a small sphere (centre c, radius rad), inflated by the margin, touches
 APT_HD void grid_cell_range(const GridHeader &h, float c, float rad, int a, uint32_t &c0, uint32_t &c1) {

@@ -7,7 +7,7 @@
 //   2  small / large classification, ordered lists by a scan, bounding box of the small spheres   -> 40-byte read-back
 //   3  cell counts (atomics), exclusive scan over the cells                                          -> 4-byte read-back
 //   4  items scattered through per-cell cursors, every cell's list sorted (ascending sphere index, as the host's: short
-//      lists on the device, lists longer than 32 items on the host), geometry tables
+//      lists on the device, lists longer than 32 items on the host), geometry tables, pair-slot tables
 // Synchronous on `stream` (two small read-backs size the buffer); a build step, not a render call.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -211,6 +211,13 @@ __global__ __launch_bounds__(256) void grid_geom_kernel(const float *__restrict_
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i < ns) geom[i] = make_float4(sph[ns + i], sph[2 * (size_t)ns + i], sph[3 * (size_t)ns + i], sph[i]);
     if (i < nitems) { const uint32_t k = items[i]; item_geom[i] = make_float4(sph[ns + k], sph[2 * (size_t)ns + k], sph[3 * (size_t)ns + k], sph[k]); }
+}
+
+// pair-slot tables (pt_core.h): one thread per cell, thread ncells the always-tested list; after grid_geom_kernel
+__global__ __launch_bounds__(256) void grid_slots_kernel(uint32_t *__restrict__ w, GridHeader h, const float *__restrict__ sph) {
+    const uint32_t c = blockIdx.x * 256 + threadIdx.x;
+    if (c <= h.ncells) grid_fill_cell_slots(w, h, c);
+    if (c < h.num_spheres) grid_fill_sphere8(w, h, sph, c);
 }
 
 } // namespace

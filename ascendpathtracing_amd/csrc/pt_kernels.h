@@ -165,6 +165,7 @@ template <int MODE, int SC, int GROUP, bool RETIRE, bool TWO = false>
 __global__ __launch_bounds__(kBlock, TWO ? APT_TWO_WAVES : (RETIRE && SC == kScene8 && GROUP == 8) ? APT_QUEUE_WAVES : (SC == kSceneGrid ? APT_GRID_WAVES : (SC == kSceneTiles ? APT_TILE_WAVES : APT_FULL_WAVES))) void render_frame_kernel(const float *__restrict__ sph, FrameArgs fa,
                                                               TraceArgs ta, LeafProg lp) {
     constexpr bool NS8 = SC == kScene8;
+    if (SC == kSceneGrid && ta.grid_walk == 2u && grid_queue_usable(ta)) return;   // the sample-queue kernel's grid form renders this frame (pt_queue.h)
     __shared__ float4 tab[kTab8Floats4];
     __shared__ float4 tile[SC == kSceneTiles ? kTile : 1];
     extern __shared__ float dyn_lds[];
@@ -458,7 +459,9 @@ __global__ __launch_bounds__(kBlock, TWO ? APT_TWO_WAVES : (RETIRE && SC == kSce
             }
             const uint32_t nt = n - nfull;
             if (nt) { // res += a[i] for the n % 8 trailing samples, in order
+                const uint32_t traced_before = traced;
                 const Col c = sample(start + nfull + (j < nt ? j : 0));
+                if (j >= nt) traced = traced_before;   // lanes past the tail re-trace its first sample: not a segment of the frame (statistic only)
                 for (uint32_t t = 0; t < nt; ++t) {
                     const int src = (int)((lane & ~7u) + t);
                     acc[0] = acc[0] + __shfl(c.r, src, 64);

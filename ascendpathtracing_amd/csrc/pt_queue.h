@@ -49,6 +49,7 @@ struct QueueArgs {
     uint32_t ppw;        // pixels per wave
     uint32_t nbuf;       // colour buffers = units that may be in flight (>= 2)
     uint32_t buf_bytes;  // bytes per colour buffer: queue_buf_bytes(maxleaf)
+    uint32_t retire;     // grid form: 1 = APT_FLAG_RETIRE (finished paths stop), 0 = every path traces `depth` segments
 };
 // A colour buffer holds the 4 * n items of a unit as [sub-pixel][sample][3] floats, every sub-pixel's block shifted by 4 more
 // bytes (a block of n * 12 bytes is a multiple of 256 bytes for n = 64: the four chains of a lane group would hit the same banks).
@@ -69,10 +70,15 @@ __host__ __device__ inline uint32_t queue_lds_bytes(bool rr, uint32_t nbuf, bool
 #ifndef APT_QUEUE8_WAVES
 #define APT_QUEUE8_WAVES 5 // waves per SIMD the register budget of render_frame_queue8_kernel is set for (96 VGPRs; its 8.6 KB of LDS allow 18 waves per CU at S = 64)
 #endif
+#ifndef APT_QUEUE_GRID_WAVES
+#define APT_QUEUE_GRID_WAVES 5 // the grid form (SC == kSceneGrid) carries a DDA state per lane; 4 / 5 waves measured: 252 / 238 ms at C4 (225 / 213 with retirement)
+#endif
 // RR: APT_FLAG_RR (the host picks the instantiation from ta.rr_start): without it the kernel carries no roulette key and no
 // per-bounce test of the flag.
-template <int MODE, bool RR>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(APT_QUEUE8_WAVES, APT_QUEUE8_WAVES))) void render_frame_queue8_kernel(const float *__restrict__ sph, FrameArgs fa, TraceArgs ta,
+// SC == kScene8: the reference's 8 spheres (SGPR scene, fast bounce block).  SC == kSceneGrid: any scene through the pair-slot
+// tables of the uniform grid (apt_render_params.accel), every lane at its own place of its own walk: run_grid() below.
+template <int MODE, bool RR, int SC = kScene8>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SC == kSceneGrid ? APT_QUEUE_GRID_WAVES : APT_QUEUE8_WAVES, SC == kSceneGrid ? APT_QUEUE_GRID_WAVES : APT_QUEUE8_WAVES))) void render_frame_queue8_kernel(const float *__restrict__ sph, FrameArgs fa, TraceArgs ta,
                                                                  LeafProg lp, QueueArgs qa) {
     extern __shared__ __align__(16) unsigned char qlds[];
     float4 *tab = reinterpret_cast<float4 *>(qlds + queue_lds_off_tab());
@@ -81,9 +87,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(APT_QUEUE8_W
     // No static LDS in this kernel, so the dynamic region starts at LDS address 0 (tests/test_isa_hazards.py checks the kernel
     // descriptor's group_segment_fixed_size); a build that breaks this renders nothing rather than reading the wrong pool entries.
     if ((uint32_t)(uintptr_t)qlds != 0u) return;
+    if (SC == kSceneGrid && !grid_queue_usable(ta)) return;            // wave-uniform: render_frame_kernel renders this frame (grid_walk == 2)
     if (lane < sizeof(Camera) / sizeof(double)) (&cam.pos[0])[lane] = (&fa.cam.pos[0])[lane];
     Scene8 sc;
-    const Tab8 tab8 = load_scene8(sph, sc, tab); // ends with a barrier
+    Tab8 tab8{tab, tab + 8};
+    if (SC == kScene8) tab8 = load_scene8(sph, sc, tab); // ends with a barrier
+    else { sc.planes = false; __syncthreads(); }
     const KeyConsts kc = make_key_consts(ta.eps);
     const bool fast_ok = eps_allows_rootkey(ta.eps);
     constexpr bool rr = RR;
@@ -368,15 +377,289 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(APT_QUEUE8_W
             step(s, planes_tag);
         }
     };
-    if (sc.planes) run(std::true_type{});
+    // ---- SC == kSceneGrid: any scene through the grid's pair-slot tables, every lane at its own place of its own walk -----------
+    // Why this form.  The nested walk of render_frame_kernel (pt_trace.h grid_segment) is bound by the CU's vector-memory ADDRESS
+    // path, not by arithmetic or latency: its TA is 90-96 % busy (profiles/r03_grid_ta_pmc.json), and a wave-level load costs that
+    // unit the same ~7 (dword) / ~17 (dwordx4) cycles whether 3 or 8 of its lanes are active (profiles/microbench/ta_rates.hip:
+    // the cost only grows beyond ~8 lanes, by ~2.2 cycles per L1-missing lane).  The nested form issues ~320 such loads per wave
+    // and segment, its float4 candidate loads serving 3.5 lanes on average: the inner loop runs to the longest list of the wave in
+    // every cell of the longest walk, and the lanes of finished walks idle until the slowest of 64 is through.
+    // Here a lane is WALKING or WAITING.  A walking lane does one of two things per loop turn: it tests ONE pair slot of its cell
+    // -- two candidates in the packed form of the 8-sphere kernel (intersect_pre2, exact single-rsq square root, integer root
+    // keys) -- or, its list exhausted, leaves the cell (exit test, one DDA step, ONE dword with the next cell's slot range).  A lane
+    // whose walk has ended waits; as soon as `refill_lanes` lanes wait (or nobody walks) the per-segment block runs for all of them
+    // together: shading step, roulette, park / refill from the ray pool, always-tested spheres, slab test, DDA set-up.
+    // The arg-min is a 64-bit (root key, sphere id) minimum: on equal t the lower sphere index wins, as in the reference's strict
+    // '<' loop over ascending indices, with no tie bookkeeping (a sphere met again in the next cell yields the same pair).
+    // Exactness: operation for operation intersect_pre / correctly rounded square root / select_root; a discriminant outside the
+    // fast square root's range (|disc| < 2^-96) is redone with sqrtf() on the spot.  Lanes whose direction is not of unit length
+    // test every sphere (trace_grid's rule).  The frame is bit-identical to render_frame_kernel's (tests/test_gpu_parity.py).
+    auto run_grid = [&]() __attribute__((always_inline)) {
+#if defined(__HIP_DEVICE_COMPILE__) // (device-only builtins below)
+        const GridHeader &h = *reinterpret_cast<const GridHeader *>(ta.grid);
+        const uint32_t *__restrict__ grid = ta.grid;
+        const uint32_t ns = ta.ns;
+        const uint32_t *cell_start = grid + h.off_cells, *cellslot = grid + h.off_cellslot, *slot_ids = grid + h.off_slot_ids;
+        const float4 *geom = reinterpret_cast<const float4 *>(grid + h.off_geom);
+        const float4 *slot_geom = reinterpret_cast<const float4 *>(grid + h.off_slots);
+        const float4 *sphere8 = reinterpret_cast<const float4 *>(grid + h.off_sphere8);
+        const int miss = (MODE == kModeOracle) ? -1 : 0;
+        // root keys (pt_trace.h KeyConsts), wave-uniform here: scalar registers
+        const uint32_t kbias = f32_bits(ta.eps) + 1u, kinit = f32_bits(kMissT) - kbias;
+        const uint64_t nbias2 = ((uint64_t)(0u - kbias) << 32) | (0x80000000u - kbias);
+        const uint64_t retire_mask = qa.retire ? ~0ull : 0ull;
+        // per-lane state of the running segment
+        uint32_t bestk = 0, bestp = 0;                          // root key of the nearest accepted root so far; where its sphere is: position 2 * slot + half in
+                                                                // slot_ids, or kIdFlag | sphere index (lanes that tested every sphere)
+        constexpr uint32_t kIdFlag = 0x80000000u, kNoPos = 0xffffffffu;
+        uint32_t pend = kNoPos;                                 // position of a candidate that tied with the running minimum (see test_pair)
+        float tm0 = 0.f, tm1 = 0.f, tm2 = 0.f, td0 = 0.f, td1 = 0.f, td2 = 0.f;
+        int inc0 = 0, inc1 = 0, inc2 = 0;                       // linear cell index increment per axis step
+        uint32_t lin = 0, rem = 0, cur = 0, end = 0;            // cell, steps left per axis (9 bits + guard bit each), POSITION cursor / end (2 per slot)
+        uint32_t n_cells = 0, n_tests = 0;                      // statistics
+        uint64_t walking = 0, has_seg = 0;                      // lanes in a walk / lanes whose registers hold a (finished or running) segment
+        constexpr uint32_t kGuard = (1u << 9) | (1u << 19) | (1u << 29);
+        auto lane_in = [&](uint64_t m) __attribute__((always_inline)) -> bool { return select_const(m, 1) != 0; };
+        // Two candidates (a pair slot) against the lane's ray; `pos` = position of the first.  Equal keys mean equal t: the lower SPHERE
+        // index must win (the reference's strict '<' over ascending indices).  Inside a slot and inside a list the ids ascend, so an
+        // earlier candidate beats a later one on a tie by order.  A tie with the running minimum from an EARLIER list -- nearly always
+        // the same sphere met again in the next cell -- is only RECORDED (`pend`: position of the tying candidate; a strictly nearer
+        // root voids it) and settled by the ids when the segment is shaded: no load, no wait in the walk.  A second tie while one is
+        // recorded (rare: a sphere met in three cells) settles the recorded one on the spot.  (If both candidates tie with the running
+        // minimum, the second has the higher id of the two and cannot matter.)
+        auto id_at = [&](uint32_t p) __attribute__((always_inline)) -> uint32_t { return (p & kIdFlag) ? (p & ~kIdFlag) : slot_ids[p]; };
+        auto test_pair = [&](const float4 a, const float4 c4, uint32_t pos) __attribute__((always_inline)) {
+            const HitPre2 hp = intersect_pre2(a, c4, s.oxy.x, s.oxy.y, s.oz, s.dxy.x, s.dxy.y, s.dz);
+            const f2 r0 = {__builtin_amdgcn_rsqf(hp.disc.x), __builtin_amdgcn_rsqf(hp.disc.y)};   // sqrt_rn_rsq1 on both halves
+            const f2 y = hp.disc * r0, hh = r0 * 0.5f;
+            const f2 res = __builtin_elementwise_fma(-y, y, hp.disc);
+            f2 q = __builtin_elementwise_fma(res, hh, y);
+            // NaN discriminants (pads, NaN spheres) drop out of the minimum: they cannot hit either way
+            if (__builtin_expect(__builtin_amdgcn_ballot_w64(min3_abs(1.0f, hp.disc.x, hp.disc.y) < 0x1p-96f) != 0, 0)) {
+                asm volatile("" ::: "memory");
+                q = f2{sqrtf(hp.disc.x), sqrtf(hp.disc.y)};
+            }
+            const uint64_t ka = root_pair<0>(hp.b, q) + nbias2, kb = root_pair<1>(hp.b, q) + nbias2;   // intersect_ns8_v2's keys
+            const uint32_t ma = min((uint32_t)ka, (uint32_t)(ka >> 32)), mb = min((uint32_t)kb, (uint32_t)(kb >> 32));
+            const bool eq_a = ma == bestk, eq_b = mb == bestk && !eq_a, tie = eq_a || eq_b;
+            if (__builtin_expect(__builtin_amdgcn_ballot_w64(tie && pend != kNoPos) != 0, 0)) {
+                if (tie && pend != kNoPos) {
+                    if (slot_ids[pend] < id_at(bestp)) bestp = pend;
+                    pend = kNoPos;
+                }
+            }
+            const bool take_a = ma < bestk;
+            bestk = take_a ? ma : bestk;
+            bestp = take_a ? pos : bestp;
+            const bool take_b = mb < bestk;
+            bestk = take_b ? mb : bestk;
+            bestp = take_b ? pos + 1u : bestp;
+            pend = (take_a || take_b) ? kNoPos : (tie ? pos + (eq_b ? 1u : 0u) : pend);
+        };
+        auto fetch_range = [&]() __attribute__((always_inline)) {
+            const uint32_t cs = cellslot[lin];
+            cur = (cs >> kGridSlotCountBits) << 1;
+            uint32_t cnt = cs & kGridSlotCountMax;
+            if (cnt == kGridSlotCountMax) cnt = (cell_start[lin + 1] - cell_start[lin] + 1u) >> 1;   // a long list (clustered scenes)
+            end = cur + 2u * cnt;
+            ++n_cells;
+        };
+        // ---- one turn of the walking lanes ----
+        auto turn = [&]() __attribute__((always_inline)) {
+            bool stop = false;                                  // (wave masks are only updated outside divergent regions)
+            const bool w = lane_in(walking);
+            const bool need = w && cur >= end;                  // list exhausted: leave the cell
+            if (__builtin_amdgcn_ballot_w64(need) != 0) {
+                if (need) {
+                    const float te = fminf(tm0, fminf(tm1, tm2));                   // parameter at which the ray leaves this cell
+                    const float tmin = bits_f32(bestk + kbias);
+                    const bool s0 = tm0 <= tm1 && tm0 <= tm2, s1 = !s0 && tm1 <= tm2;
+                    tm0 = s0 ? tm0 + td0 : tm0;
+                    tm1 = s1 ? tm1 + td1 : tm1;
+                    tm2 = (!s0 && !s1) ? tm2 + td2 : tm2;
+                    {   // lin += s0 ? inc0 : (s1 ? inc1 : inc2), written with explicit masks: the plain nested select of the three
+                        // per-lane increments ends in "illegal VGPR to SGPR copy" in this compiler's back end
+                        const uint64_t m0 = __builtin_amdgcn_ballot_w64(s0), m1 = __builtin_amdgcn_ballot_w64(s1);
+                        uint32_t sel;
+                        asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(sel) : "v"(inc2), "v"(inc1), "s"(m1));
+                        asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(sel) : "v"(sel), "v"(inc0), "s"(m0));
+                        lin += sel;
+                    }
+                    rem -= s0 ? 1u : (s1 ? 1u << 10 : 1u << 20);
+                    // nothing nearer can lie ahead, or the next cell is outside the grid (an axis with no steps left lost its guard bit)
+                    stop = tmin < te - (1e-3f * fabsf(te) + h.margin) || (rem & kGuard) != kGuard;
+                    if (!stop) fetch_range();
+                }
+            }
+            const bool has = w && !stop && cur < end;
+            if (__builtin_amdgcn_ballot_w64(has) != 0) {
+                if (has) {
+                    const float4 a = slot_geom[cur], c4 = slot_geom[cur + 1u];   // slot cur / 2: float4s 2 * slot and 2 * slot + 1
+                    test_pair(a, c4, cur);
+                    cur += 2u;
+                    n_tests += 2;
+                }
+            }
+            walking &= ~__builtin_amdgcn_ballot_w64(stop);
+        };
+        // ---- the per-segment block for the lanes of `batch` (none of them walking): finish the segment they hold, park / refill,
+        // start the next one ----
+        auto transition = [&](uint64_t batch) __attribute__((always_inline)) {
+            ++n_bounce_exec;
+            const uint64_t fin = batch & has_seg & active;     // lanes whose finished segment is shaded now
+            traced += (uint32_t)__popcll(fin);
+            if (lane_in(fin)) {
+                const float tmin = bits_f32(bestk + kbias);
+                int idx = miss;
+                if (bestk != kinit) {
+                    uint32_t id = id_at(bestp);
+                    if (pend != kNoPos) { const uint32_t idp = slot_ids[pend]; id = idp < id ? idp : id; }   // a recorded tie: the lower index wins
+                    idx = (int)id;
+                }
+                const uint32_t g = (idx < 0) ? ns - 1 : (uint32_t)idx;
+                const float4 gc = sphere8[2 * (size_t)g], col = sphere8[2 * (size_t)g + 1];   // centre, r2 | albedo: one cache line
+                PathState c = s, n;
+                c.rxy = thr_xy; c.rz = thr_z; c.alive = select_const(alive, 1);
+                n = c;
+                float amin = 1.0f;
+                shade_and_reflect<MODE, true>(n, tmin, gc.x, gc.y, gc.z, col.x, col.y, col.z, idx == ta.light, &amin);
+                if (__builtin_expect(__builtin_amdgcn_ballot_w64(amin < 0x1p-96f) != 0, 0)) {   // out of the fast sequences' range: sqrtf() and '/'
+                    asm volatile("" ::: "memory");
+                    n = c;
+                    shade_and_reflect<MODE>(n, tmin, gc.x, gc.y, gc.z, col.x, col.y, col.z, idx == ta.light);
+                }
+                if (rr) {
+                    const uint32_t d = ta.depth - 1u - left;
+                    if (d + 1u >= ta.rr_start) russian_roulette(n, key, d);
+                }
+                s.oxy = n.oxy; s.oz = n.oz; s.dxy = n.dxy; s.dz = n.dz;
+                thr_xy = n.rxy; thr_z = n.rz;
+                s.alive = n.alive;
+            }
+            alive = (alive & ~fin) | (fin & __builtin_amdgcn_ballot_w64(s.alive != 0));
+            {   // park the finished paths of `fin` (park() of the 8-sphere form, restricted to these lanes)
+                uint64_t zero, at_depth, saved;
+                uint32_t orbits;
+                asm("v_or3_b32 %0, %1, %2, %3" : "=v"(orbits) : "v"(thr_xy.x), "v"(thr_xy.y), "v"(thr_z));
+                asm("v_cmp_eq_f32_e64 %0, 0, %1" : "=s"(zero) : "v"(orbits));
+                at_depth = __builtin_amdgcn_ballot_w64(left == 0u);
+                if (lane_in(fin)) --left;
+                const uint64_t done = fin & (((~alive | zero) & retire_mask) | at_depth);
+                asm volatile("s_and_saveexec_b64 %[sv], %[m]\n\t"
+                             "ds_write_b32 %[ca], %[rx]\n\t"
+                             "ds_write_b32 %[ca], %[ry] offset:4\n\t"
+                             "ds_write_b32 %[ca], %[rz] offset:8\n\t"
+                             "s_mov_b64 exec, %[sv]"
+                             : [sv] "=&s"(saved)
+                             : [m] "s"(done), [ca] "v"(caddr), [rx] "v"(thr_xy.x), [ry] "v"(thr_xy.y), [rz] "v"(thr_z)
+                             : "scc", "memory");
+                active &= ~done;
+                has_seg &= ~done;
+            }
+            refill(s);
+            if (__builtin_expect(pool_level <= kPool - kPoolBatch && g_unit < U, 0)) {
+                bool room = g_off != 0 || g_unit - a_unit < nbuf;
+                if (!room && oldest_unit_parked()) { accumulate_unit(); room = true; }
+                if (room) { gen_batch(); refill(s); }
+            }
+            // ---- start the next segment of every active lane that is not walking ----
+            const uint64_t start = active & ~walking;
+            bool walk = false;
+            if (lane_in(start)) {
+                bestk = kinit; bestp = 0; pend = kNoPos;        // the key of kMissT: a root of exactly kMissT never wins, like the strict '<'
+                cur = end = 0;
+                const float dd = s.dxy.x * s.dxy.x + s.dxy.y * s.dxy.y + s.dz * s.dz;
+                const bool unit = fabsf(dd - 1.0f) <= 1e-3f;   // false for NaN / inf
+                if (!unit) {                                    // the roots are geometric ray parameters only for unit directions: every sphere,
+                    float tmin = kMissT;                        // in the reference's own float form
+                    uint32_t idx = 0;
+                    for (uint32_t k = 0; k < ns; ++k) {
+                        const float4 g = geom[k];
+                        const float t = intersect_sphere(g.x, g.y, g.z, g.w, s.oxy.x, s.oxy.y, s.oz, s.dxy.x, s.dxy.y, s.dz, ta.eps);
+                        if (t < tmin) { tmin = t; idx = k; }
+                        ++n_tests;
+                    }
+                    bestk = f32_bits(tmin) - kbias;             // tmin is kMissT or an accepted root: its key is exact
+                    bestp = kIdFlag | idx;
+                } else {
+                    for (uint32_t j = 0; j < h.slot_base; ++j) {    // the always-tested list: wave-uniform addresses, scalar loads
+                        test_pair(slot_geom[2 * j], slot_geom[2 * j + 1], 2 * j);
+                        n_tests += 2;
+                    }
+                }
+                if (unit) {
+                    float tn = 0.0f, tf = 3.0e38f;
+                    bool inbox = true;
+                    const float ix = __builtin_amdgcn_rcpf(s.dxy.x), iy = __builtin_amdgcn_rcpf(s.dxy.y), iz = __builtin_amdgcn_rcpf(s.dz);
+                    auto slab = [&](float o, float dv, float inv, float lo, float hi) __attribute__((always_inline)) {
+                        if (fabsf(dv) > 1e-20f) {
+                            const float t1 = (lo - o) * inv, t2 = (hi - o) * inv;
+                            tn = fmaxf(tn, fminf(t1, t2));
+                            tf = fminf(tf, fmaxf(t1, t2));
+                        } else if (!(o >= lo && o <= hi)) inbox = false;
+                    };
+                    slab(s.oxy.x, s.dxy.x, ix, h.gmin[0], h.gmax[0]);
+                    slab(s.oxy.y, s.dxy.y, iy, h.gmin[1], h.gmax[1]);
+                    slab(s.oz, s.dz, iz, h.gmin[2], h.gmax[2]);
+                    if (inbox && tn <= tf) {
+                        auto axis = [&](float o, float dv, float inv, float lo, float cellw, float invw, int na, int stride, int &c, int &inc,
+                                        uint32_t &steps, float &tmax, float &tdel) __attribute__((always_inline)) {
+                            int ci = (int)floorf((o + dv * tn - lo) * invw);
+                            ci = ci < 0 ? 0 : (ci >= na ? na - 1 : ci);
+                            c = ci;
+                            if (dv > 1e-20f) { inc = stride; steps = (uint32_t)(na - 1 - ci); tmax = (lo + (float)(ci + 1) * cellw - o) * inv; tdel = cellw * inv; }
+                            else if (dv < -1e-20f) { inc = -stride; steps = (uint32_t)ci; tmax = (lo + (float)ci * cellw - o) * inv; tdel = -cellw * inv; }
+                            else { inc = 0; steps = 0; tmax = 3.0e38f; tdel = 3.0e38f; }   // never the nearest crossing of a unit direction within kMissT
+                        };
+                        int c0, c1, c2;
+                        uint32_t l0, l1, l2;
+                        const int n0 = (int)h.n[0], n1 = (int)h.n[1], n2 = (int)h.n[2];
+                        axis(s.oxy.x, s.dxy.x, ix, h.gmin[0], h.cell[0], h.inv_cell[0], n0, 1, c0, inc0, l0, tm0, td0);
+                        axis(s.oxy.y, s.dxy.y, iy, h.gmin[1], h.cell[1], h.inv_cell[1], n1, n0, c1, inc1, l1, tm1, td1);
+                        axis(s.oz, s.dz, iz, h.gmin[2], h.cell[2], h.inv_cell[2], n2, n0 * n1, c2, inc2, l2, tm2, td2);
+                        lin = (uint32_t)((c2 * n1 + c1) * n0 + c0);
+                        rem = kGuard | l0 | l1 << 10 | l2 << 20;
+                        fetch_range();
+                        walk = true;
+                    }
+                }
+            }
+            walking |= __builtin_amdgcn_ballot_w64(walk);
+            has_seg |= start;
+        };
+        const uint32_t batch_lanes = ta.refill_lanes;          // waiting lanes that trigger the per-segment block (apt_set_refill_lanes; default 32)
+        // upper bound of the loop turns (a turn advances a walking lane by a cell or a slot, or a transition issues / shades):
+        // protection against a logic error, never reached
+        uint64_t turns_left = ((uint64_t)npx * 4u * S * ((uint64_t)ta.depth + 1u) + 64u) * ((uint64_t)h.n[0] + h.n[1] + h.n[2] + 5u + h.nslots);
+        for (;;) {
+            const uint64_t waiting = ~walking;                  // finished segments, fresh lanes and lanes without a path
+            const uint32_t nwait = (uint32_t)__popcll(waiting & active) + ((pool_level != 0 || g_unit < U) ? (uint32_t)__popcll(~active) : 0u);
+            if (walking == 0 || nwait >= batch_lanes) {
+                transition(waiting);
+                if (active == 0) break;                         // nothing runs, nothing could be issued: everything is parked
+            }
+            if (turns_left-- == 0u) break;
+            turn();
+        }
+        if (ta.traced) {                                        // statistics: cells visited / candidates tested (grid_stats)
+            unsigned long long c = n_cells, t = n_tests;
+            for (int off = 32; off > 0; off >>= 1) { c += __shfl_xor(c, off, 64); t += __shfl_xor(t, off, 64); }
+            if (lane == 0) { atomicAdd(ta.traced + 1, c); atomicAdd(ta.traced + 2, t); }
+        }
+#endif
+    };
+    if (SC == kSceneGrid) run_grid();
+    else if (sc.planes) run(std::true_type{});
     else run(std::false_type{});
     // No lane is active, the pool is empty and every unit has been generated: every item is parked.
     while (a_unit < U) accumulate_unit();
 
     if (ta.traced && lane == 0) {
         atomicAdd(ta.traced, (unsigned long long)traced);
-        atomicAdd(ta.traced + 1, 64ull * n_bounce_exec);
-        atomicAdd(ta.traced + 2, 64ull * n_gen_exec);
+        if (SC != kSceneGrid) {                                 // (the grid form reports its walk statistics in these two slots)
+            atomicAdd(ta.traced + 1, 64ull * n_bounce_exec);
+            atomicAdd(ta.traced + 2, 64ull * n_gen_exec);
+        }
         if (n_exact) atomicAdd(ta.traced + 3, (unsigned long long)n_exact);
     }
 }

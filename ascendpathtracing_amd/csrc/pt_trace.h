@@ -72,6 +72,8 @@ struct TraceArgs {
     uint32_t rr_start;          // Russian roulette (APT_FLAG_RR): first bounce count it applies at; 0 = off
     uint64_t seed;              // keys the roulette draws
     const uint32_t *grid;       // apt_render_params.accel (device) or null
+    uint32_t grid_walk;         // frame kernels: 0 = render_frame_kernel walks the grid (nested item walk); 2 = it returns at once when
+                                // the sample-queue kernel's grid form renders this frame (grid_queue_usable)
     unsigned long long *traced; // optional device counter of traced segments
 };
 
@@ -847,6 +849,15 @@ __device__ __forceinline__ void grid_segment(const GridCtx &ctx, PathState &s, b
         shade_and_reflect<MODE>(s, tmin, gc.x, gc.y, gc.z, colx[g], coly[g], colz[g], idx == ta.light);
 #endif
     }
+}
+
+// Can the sample-queue kernel's grid form (pt_queue.h run_grid) render with this grid?  Wave-uniform, read from the buffer
+// itself on the device (no host read-back in the launch path): the grid is this scene's, carries the pair-slot tables,
+// and eps permits the integer root keys.  The host launches BOTH kernels for such a frame (TraceArgs.grid_walk == 2): the one
+// this predicate does not select returns at once.
+__device__ __forceinline__ bool grid_queue_usable(const TraceArgs &ta) {
+    const GridHeader *h = reinterpret_cast<const GridHeader *>(ta.grid);
+    return h && h->magic == kGridMagic && h->num_spheres == ta.ns && h->off_cellslot != 0 && eps_allows_rootkey(ta.eps);
 }
 
 template <int MODE, bool RETIRE>

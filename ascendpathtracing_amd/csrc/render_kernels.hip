@@ -70,6 +70,7 @@ TraceArgs make_trace_args(const apt_render_params *p, const apt_context::Values 
     ta.eps = p->eps; ta.gain = p->gain; ta.traced = cv.trace_counter;
     ta.refill_lanes = cv.refill_lanes;
     ta.grid = (p->num_spheres != 8) ? reinterpret_cast<const uint32_t *>((uintptr_t)p->accel) : nullptr;
+    ta.grid_walk = 0;
     ta.emission = (p->flags & APT_FLAG_EMISSION) ? 1u : 0u;
     ta.rr_start = (p->flags & APT_FLAG_RR) ? (p->rr_start ? p->rr_start : 3u) : 0u;
     ta.seed = p->seed;
@@ -174,6 +175,7 @@ int do_render_frame(const apt_context::Values &cv, const apt_render_params *p, v
         const uint32_t unit_items = 4u * lp.maxleaf;
         qa.nbuf = std::max(2u, std::min(16u, (512u + unit_items - 1u) / unit_items));
         qa.buf_bytes = queue_buf_bytes(lp.maxleaf);
+        qa.retire = 1u;
         // pixels per wave: 16 at C2 (lane efficiency 0.98; 8 / 16 / 24 measured within 0.5 % of each other, 2 costs 6 %), fewer only
         // for frames too small to fill the chip's ~3800 wave slots a few times over
         uint64_t ppw = std::max<uint64_t>(4, std::min<uint64_t>(16, pixel_count / 8192u));
@@ -195,17 +197,46 @@ int do_render_frame(const apt_context::Values &cv, const apt_render_params *p, v
         hipError_t e = hipGetLastError();
         return e == hipSuccess ? APT_OK : hip_fail(e);
     }
+    TraceArgs ta_frame = ta;
+    if (!ns8 && ta.grid && group == 8 && p->depth > 0 && !(getenv("APT_GRID_WALK") && getenv("APT_GRID_WALK")[0] == 'i')) {
+        // A scene behind a grid: the sample-queue kernel's grid form (pt_queue.h run_grid), with or without APT_FLAG_RETIRE.  Whether
+        // the grid carries the pair-slot tables that form needs is written in the buffer on the DEVICE: rather than reading it back in
+        // the launch path, both kernels are launched and each asks grid_queue_usable() -- the one not chosen returns at once.
+        // (APT_GRID_WALK=items: measurement knob, the nested item walk of render_frame_kernel only.)
+        QueueArgs qa;
+        const uint32_t unit_items = 4u * lp.maxleaf;
+        qa.nbuf = std::max(2u, std::min(16u, (512u + unit_items - 1u) / unit_items));
+        qa.buf_bytes = queue_buf_bytes(lp.maxleaf);
+        qa.retire = retire ? 1u : 0u;
+        uint64_t ppw = std::max<uint64_t>(4, std::min<uint64_t>(16, pixel_count / 8192u));
+        if (const char *env = getenv("APT_QUEUE_PPW")) { const long v = atol(env); if (v >= 1 && v <= 4096) ppw = (uint64_t)v; }
+        qa.ppw = (uint32_t)ppw;
+        const uint64_t waves = (pixel_count + ppw - 1) / ppw;
+        if (waves > 0x7fffffffull) return fail(APT_ERR_ARG, "pixel_count too large for one launch; shard it%s");
+        const size_t qlds = queue_lds_bytes(ta.rr_start != 0, qa.nbuf, lp.nleaves > 1, qa.buf_bytes);
+        const bool rrk = ta.rr_start != 0;
+        if (p->mode == APT_MODE_ORACLE) {
+            if (rrk) hipLaunchKernelGGL((render_frame_queue8_kernel<kModeOracle, true, kSceneGrid>), dim3((unsigned)waves), dim3(64), qlds, st, spheres, fa, ta, lp, qa);
+            else hipLaunchKernelGGL((render_frame_queue8_kernel<kModeOracle, false, kSceneGrid>), dim3((unsigned)waves), dim3(64), qlds, st, spheres, fa, ta, lp, qa);
+        } else {
+            if (rrk) hipLaunchKernelGGL((render_frame_queue8_kernel<kModeKernel, true, kSceneGrid>), dim3((unsigned)waves), dim3(64), qlds, st, spheres, fa, ta, lp, qa);
+            else hipLaunchKernelGGL((render_frame_queue8_kernel<kModeKernel, false, kSceneGrid>), dim3((unsigned)waves), dim3(64), qlds, st, spheres, fa, ta, lp, qa);
+        }
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return hip_fail(e);
+        ta_frame.grid_walk = 2;
+    }
     size_t lds = lp.nleaves > 1 ? (size_t)kMaxStack * 3 * kStackSlots * sizeof(float) : 0;
     if (retire && (ns8 || !ta.grid) && group == 8) lds += (size_t)(kBlock / 64) * 3 * 8 * lp.maxleaf * sizeof(float); // colour queue
     const dim3 grid((unsigned)blocks);
     const int sck = ns8 ? kScene8 : (ta.grid ? kSceneGrid : kSceneTiles);
     if (p->mode == APT_MODE_ORACLE) {
         if (sck == kScene8) launch_frame_g<kModeOracle, kScene8>(group, retire, grid, lds, st, spheres, fa, ta, lp);
-        else if (sck == kSceneGrid) launch_frame_g<kModeOracle, kSceneGrid>(group, retire, grid, lds, st, spheres, fa, ta, lp);
+        else if (sck == kSceneGrid) launch_frame_g<kModeOracle, kSceneGrid>(group, retire, grid, lds, st, spheres, fa, ta_frame, lp);
         else launch_frame_g<kModeOracle, kSceneTiles>(group, retire, grid, lds, st, spheres, fa, ta, lp);
     } else {
         if (sck == kScene8) launch_frame_g<kModeKernel, kScene8>(group, retire, grid, lds, st, spheres, fa, ta, lp);
-        else if (sck == kSceneGrid) launch_frame_g<kModeKernel, kSceneGrid>(group, retire, grid, lds, st, spheres, fa, ta, lp);
+        else if (sck == kSceneGrid) launch_frame_g<kModeKernel, kSceneGrid>(group, retire, grid, lds, st, spheres, fa, ta_frame, lp);
         else launch_frame_g<kModeKernel, kSceneTiles>(group, retire, grid, lds, st, spheres, fa, ta, lp);
     }
     hipError_t e = hipGetLastError();
@@ -548,6 +579,7 @@ int apt_build_grid_device(const float *spheres_dev, uint32_t ns, void *stream, v
                     const uint32_t ng = ns > nitems ? ns : nitems;
                     if (!break_out) hipLaunchKernelGGL(grid_geom_kernel, dim3((ng + 255) / 256), dim3(256), 0, st, spheres_dev, ns, w + h.off_items, nitems,
                                        reinterpret_cast<float4 *>(w + h.off_geom), reinterpret_cast<float4 *>(w + h.off_item_geom));
+                    if (!break_out && h.off_cellslot) hipLaunchKernelGGL(grid_slots_kernel, dim3((std::max(h.ncells + 1u, ns) + 255u) / 256u), dim3(256), 0, st, w, h, spheres_dev);
                     if (e == hipSuccess) e = hipGetLastError();
                     if (e == hipSuccess) e = hipStreamSynchronize(st);       // the workspace is freed below
                 }

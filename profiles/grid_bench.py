@@ -16,7 +16,10 @@ ap.add_argument("--ns", type=int, default=10000)
 ap.add_argument("--depth", type=int, default=8)
 ap.add_argument("--stats", action="store_true")
 ap.add_argument("--retire", action="store_true")
+ap.add_argument("--refill", type=int, default=0, help="apt_set_refill_lanes: waiting lanes that trigger the per-segment block of the queue kernel's grid form")
 args = ap.parse_args()
+if args.refill:
+    render.set_refill_lanes(args.refill)
 scene_h = gen_data.gen_scene(args.ns, seed=1)
 scene = torch.from_numpy(scene_h).cuda()
 t0 = time.time()
@@ -39,7 +42,7 @@ for _ in range(args.reps):
     a.record(); fb, u8 = render.render_frame(p, scene); b.record(); torch.cuda.synchronize()
     best = min(best, a.elapsed_time(b))
 seg = p.num_paths * args.depth
-out = {"ns": args.ns, "S": args.s, "depth": args.depth, "ms": round(best, 3), "nominal_gray_per_s": round(seg / best / 1e6, 2),
+out = {"refill": args.refill, "ns": args.ns, "S": args.s, "depth": args.depth, "ms": round(best, 3), "nominal_gray_per_s": round(seg / best / 1e6, 2),
        "sha256_u8": hashlib.sha256(u8.cpu().numpy().tobytes()).hexdigest()[:16],
        "grid_build_host_s": round(t_grid, 4), "grid_build_device_s": round(t_dev, 4), "grid_build_device_first_call_s": round(t_first, 4),
        "grid_bytes": int(grid.numel() * 4)}

@@ -126,6 +126,37 @@ def test_grid_builder_layout(apt):
     geom = g[off_geom:off_geom + 4 * ns].view(np.float32).reshape(ns, 4)
     tab = scene[:10 * ns].reshape(10, ns)
     assert np.array_equal(geom[:, 0], tab[1]) and np.array_equal(geom[:, 3], tab[0])
+    # round 3: the pair-slot tables of the sample-queue kernel's grid form (pt_core.h GridHeader)
+    full = g[:32]
+    off_cellslot, off_slots, off_slot_ids, nslots, slot_base, off_sphere8 = (int(x) for x in full[26:32])
+    assert off_cellslot and off_slots % 8 == 0 and off_sphere8 % 8 == 0 and slot_base == (nlarge + 1) // 2
+    slot_geom = g[off_slots:off_slots + 8 * nslots].reshape(nslots, 8)
+    slot_ids = g[off_slot_ids:off_slot_ids + 2 * nslots].reshape(nslots, 2)
+    gw = g[off_geom:off_geom + 4 * ns].reshape(ns, 4)                        # raw words (NaN-safe comparisons)
+
+    def check_list(first_slot, ids):
+        for k, sid in enumerate(ids):
+            sl, half = first_slot + k // 2, k % 2
+            assert slot_ids[sl, half] == sid and np.array_equal(slot_geom[sl, half::2], gw[sid])
+        if len(ids) % 2:                                                       # odd list: a NaN sphere with no id pads the last slot
+            sl = first_slot + len(ids) // 2
+            assert slot_ids[sl, 1] == 0xffffffff and (slot_geom[sl, 1::2] == 0x7fc00000).all()
+
+    check_list(0, g[off_large:off_large + nlarge].tolist())
+    used = np.zeros(nslots, dtype=bool)
+    used[:slot_base] = True
+    for c in range(ncells):
+        b, e = int(starts[c]), int(starts[c + 1])
+        entry = int(g[off_cellslot + c])
+        first, cnt = entry >> 6, entry & 63
+        assert first == slot_base + ((b + c + 1) >> 1) and cnt == min((e - b + 1) // 2, 63)
+        n_sl = (e - b + 1) // 2
+        assert not used[first:first + n_sl].any() and first + n_sl <= nslots   # lists never overlap
+        used[first:first + n_sl] = True
+        if c % max(1, ncells // 50) == 0:
+            check_list(first, items[b:e].tolist())
+    s8 = g[off_sphere8:off_sphere8 + 8 * ns].view(np.float32).reshape(ns, 8)
+    assert np.array_equal(s8[:, :3].T, tab[1:4]) and np.array_equal(s8[:, 3], tab[0]) and np.array_equal(s8[:, 4:7].T, tab[7:10])
 
 
 def test_missing_library_fails_loudly(apt, monkeypatch, tmp_path):
