@@ -217,6 +217,20 @@ def extras(torch, apt, render, gen_data, cfg, sph, steps):
         torch.cuda.empty_cache()
     except Exception as e:                   # noqa: BLE001
         out["c2_exact_reference_pipeline_fused"] = {"error": repr(e)[:200]}
+    try:                                     # (e) BASELINE config C4: 10 000 spheres behind the uniform grid, 256 spp (sample-queue kernel, grid form)
+        import numpy as np
+        ns4 = 10000
+        scene4 = torch.from_numpy(gen_data.gen_scene(ns4, seed=1)).cuda()
+        grid4 = gen_data.build_grid_device(scene4, ns4)
+        torch.cuda.synchronize()
+        p4 = apt.make_params(W, H, S, depth=D, num_spheres=ns4, accel=grid4.data_ptr())
+        ms_full = timed(torch, lambda: render.render_frame(p4, scene4), 2)
+        ms_ret = timed(torch, lambda: render.render_frame(p4.copy(flags=apt.APT_FLAG_RETIRE), scene4), 2)
+        out["c4_grid_10k_spheres"] = {"kernel_ms": round(ms_full, 3), "retire_kernel_ms": round(ms_ret, 3), "nominal_mray_per_s": round(nominal / ms_full / 1e3, 1),
+                                      "kernel": "render_frame_queue8_kernel<..., grid> (pt_queue.h run_grid); frame bit-identical to the brute-force traversal"}
+        del scene4, grid4
+    except Exception as e:                   # noqa: BLE001
+        out["c4_grid_10k_spheres"] = {"error": repr(e)[:200]}
     return out
 
 

@@ -282,7 +282,10 @@ int apt_gen_scene_host(uint32_t num_spheres, uint64_t seed, float *spheres,
  * passes that address in apt_render_params.accel.  Pass grid == NULL to query the size.  Rendering
  * with it is bit-identical to rendering without: every candidate goes through the reference's exact
  * intersection arithmetic, the traversal only skips spheres that provably cannot be hit, and ties keep
- * the lowest sphere index. */
+ * the lowest sphere index.  The buffer holds two forms of the lists: item ranges (the nested walk of buffer
+ * mode and of samples < 8) and, since round 3, pair-slot tables (two candidates per 32-byte slot, one word per
+ * cell) for the frame kernel's per-lane walk; apt_render_frame picks the kernel from what the buffer carries,
+ * on the device. */
 int apt_build_grid_host(const float *spheres_host, uint32_t num_spheres, void *grid, size_t *out_bytes);
 
 /* The same grid built ON THE DEVICE from the [10][Ns] table in device memory: byte-identical to what
