@@ -1,5 +1,7 @@
-// pt_queue.h -- the fused frame kernel with active-ray compaction for the reference's 8-sphere scene
-// (APT_FLAG_RETIRE, samples >= 8): render_frame_queue8_kernel.  Included by pt_kernels.h.
+// pt_queue.h -- the fused frame kernel with active-ray compaction: render_frame_queue8_kernel.  Included by pt_kernels.h.
+//   SC == kScene8     the reference's 8-sphere scene with APT_FLAG_RETIRE, samples >= 8 (what the text below describes)
+//   SC == kSceneGrid  any scene behind the uniform grid's pair-slot tables, with or without APT_FLAG_RETIRE: the same pixel
+//                     stream, ray pool and colour ring around a per-lane grid walk (run_grid(), near the end of the kernel)
 //
 // Round 3 rewrite of the wave-level sample queue (round 2: one ray slot per lane in registers, ray-generate for the
 // whole wave whenever >= 32 lanes had an empty slot, the queue drained at every pairwise leaf; the flag returned
@@ -428,7 +430,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SC == kScene
         // recorded (rare: a sphere met in three cells) settles the recorded one on the spot.  (If both candidates tie with the running
         // minimum, the second has the higher id of the two and cannot matter.)
         auto id_at = [&](uint32_t p) __attribute__((always_inline)) -> uint32_t { return (p & kIdFlag) ? (p & ~kIdFlag) : slot_ids[p]; };
-        auto test_pair = [&](const float4 a, const float4 c4, uint32_t pos) __attribute__((always_inline)) {
+        // `ties_tag` false: the list is the segment's first (the always-tested one), there is no earlier minimum to tie with.
+        auto test_pair = [&](const float4 a, const float4 c4, uint32_t pos, auto ties_tag) __attribute__((always_inline)) {
+            constexpr bool TIES = decltype(ties_tag)::value;
             const HitPre2 hp = intersect_pre2(a, c4, s.oxy.x, s.oxy.y, s.oz, s.dxy.x, s.dxy.y, s.dz);
             const f2 r0 = {__builtin_amdgcn_rsqf(hp.disc.x), __builtin_amdgcn_rsqf(hp.disc.y)};   // sqrt_rn_rsq1 on both halves
             const f2 y = hp.disc * r0, hh = r0 * 0.5f;
@@ -441,8 +445,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SC == kScene
             }
             const uint64_t ka = root_pair<0>(hp.b, q) + nbias2, kb = root_pair<1>(hp.b, q) + nbias2;   // intersect_ns8_v2's keys
             const uint32_t ma = min((uint32_t)ka, (uint32_t)(ka >> 32)), mb = min((uint32_t)kb, (uint32_t)(kb >> 32));
-            const bool eq_a = ma == bestk, eq_b = mb == bestk && !eq_a, tie = eq_a || eq_b;
-            if (__builtin_expect(__builtin_amdgcn_ballot_w64(tie && pend != kNoPos) != 0, 0)) {
+            const bool eq_a = TIES && ma == bestk, eq_b = TIES && mb == bestk && !eq_a, tie = eq_a || eq_b;
+            if (TIES && __builtin_expect(__builtin_amdgcn_ballot_w64(tie && pend != kNoPos) != 0, 0)) {
                 if (tie && pend != kNoPos) {
                     if (slot_ids[pend] < id_at(bestp)) bestp = pend;
                     pend = kNoPos;
@@ -454,7 +458,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SC == kScene
             const bool take_b = mb < bestk;
             bestk = take_b ? mb : bestk;
             bestp = take_b ? pos + 1u : bestp;
-            pend = (take_a || take_b) ? kNoPos : (tie ? pos + (eq_b ? 1u : 0u) : pend);
+            if (TIES) pend = (take_a || take_b) ? kNoPos : (tie ? pos + (eq_b ? 1u : 0u) : pend);
         };
         auto fetch_range = [&]() __attribute__((always_inline)) {
             const uint32_t cs = cellslot[lin];
@@ -495,7 +499,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SC == kScene
             if (__builtin_amdgcn_ballot_w64(has) != 0) {
                 if (has) {
                     const float4 a = slot_geom[cur], c4 = slot_geom[cur + 1u];   // slot cur / 2: float4s 2 * slot and 2 * slot + 1
-                    test_pair(a, c4, cur);
+                    test_pair(a, c4, cur, std::true_type{});
                     cur += 2u;
                     n_tests += 2;
                 }
@@ -583,7 +587,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SC == kScene
                     bestp = kIdFlag | idx;
                 } else {
                     for (uint32_t j = 0; j < h.slot_base; ++j) {    // the always-tested list: wave-uniform addresses, scalar loads
-                        test_pair(slot_geom[2 * j], slot_geom[2 * j + 1], 2 * j);
+                        test_pair(slot_geom[2 * j], slot_geom[2 * j + 1], 2 * j, std::false_type{});
                         n_tests += 2;
                     }
                 }

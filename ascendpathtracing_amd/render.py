@@ -230,7 +230,8 @@ class TraceCounter:
     @property
     def stats(self):
         """(traced segments, lane-slots spent in bounce executions, lane-slots spent in ray-generate) --
-        the last two only from the refill loop of render_frame with APT_FLAG_RETIRE."""
+        the last two only from the refill loop of render_frame with APT_FLAG_RETIRE; for scenes behind a grid
+        they are (cells visited, candidates tested) instead."""
         return tuple(int(x) for x in self.buf[:3].tolist())
 
     @property
