@@ -9,8 +9,9 @@
 // one workgroup per such pixel GROUP, started from a host-made raw generator state of block g * 2 S
 // (apt_mt19937_checkpoints_window with stride 2 S).  The workgroup
 //   * extends the generator's RAW word sequence y[n + 624] = f(y[n], y[n + 1], y[n + 397]) in a 4096-word ring in LDS, 227 new
-//     words per step (the largest chunk whose inputs are all older than the chunk: ONE barrier per step, no phases); tempering
-//     happens in the registers of the thread that consumes a word,
+//     words at a time (the largest chunk whose inputs are all older than the chunk) and 227 + 227 + 169 = 623 words per barrier: the
+//     far operand of a thread's second (third) word is the first (second) word it has just made; tempering happens in the registers of the thread that
+//     consumes a word,
 //   * works through its 312 S paths in rounds of 512 consecutive paths, TWO per thread (t and 256 + t: the two-paths-per-lane
 //     bounce of pt_trace2.h): float64 camera maths, all bounces, colour = throughput * gain,
 //   * puts the 512 colours of a round into LDS, where each run of S consecutive samples (one sub-pixel) is summed exactly as
@@ -29,7 +30,8 @@ namespace {
 constexpr uint32_t kMtGroupPixels = 78;      // 78 pixels * 4 S paths = 2 S generator blocks of 156 paths (S a power of two)
 constexpr uint32_t kMtRing = 4096;           // raw generator words kept in LDS (a round reads 2048, the recurrence reaches 624 back)
 constexpr uint32_t kMtRound = 512;           // paths per round: two per thread
-constexpr uint32_t kMtStep = 227;            // new words per generation step: y[n + 624] needs y[n + 397], so 624 - 397 at a time
+constexpr uint32_t kMtStep = 227;            // new words per chunk: y[n + 624] needs y[n + 397], so 624 - 397 at a time
+constexpr uint32_t kMtThird = 169;           // threads that can make a third word in the same step (624 - 455)
 
 __device__ __forceinline__ uint32_t mt_temper_word(uint32_t y) {
     y ^= y >> 11;
@@ -72,16 +74,27 @@ __global__ __launch_bounds__(kBlock, APT_TWO_WAVES) void render_frame_mt_kernel(
     const uint32_t nrounds = (npaths + kMtRound - 1) / kMtRound;
     for (uint32_t r = 0; r < nrounds; ++r) {
         // ---- extend the raw sequence to the words this round reads: [2048 r, 2048 r + 2048) ----
-        // (ring safety: a step writes y[have .. have + 227) over y[have - 4096 ..), and the oldest word still needed is
-        //  min(2048 r, have - 624): with have <= 2048 (r + 1) + 227 that is less than 2503 words back)
+        // (ring safety: a step writes y[have .. have + 623) over y[have - 4096 ..), and the oldest word still needed is
+        //  min(2048 r, have - 624): with have <= 2048 (r + 1) + 622 that is less than 2671 words back)
         const uint32_t need = min(4u * npaths, 2048u * (r + 1u));
         while (have < need) {
             if (t < kMtStep) {
-                const uint32_t nn = have - 624u + t;           // y[nn + 624] = y[nn + 397] ^ twist(y[nn], y[nn + 1])
-                const uint32_t y = (ring[nn & (kMtRing - 1u)] & 0x80000000u) | (ring[(nn + 1u) & (kMtRing - 1u)] & 0x7fffffffu);
-                ring[(nn + 624u) & (kMtRing - 1u)] = ring[(nn + 397u) & (kMtRing - 1u)] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+                // y[n + 624] = y[n + 397] ^ twist(y[n], y[n + 1]).  Thread t makes y[nn + 624] and then y[nn + 227 + 624] as well: its "397
+                // back" operand, y[nn + 227 + 397], IS the word the thread has just made, the other two are old words -- two chunks
+                // of 227 words per barrier.
+                const uint32_t nn = have - 624u + t;
+                auto twist = [](uint32_t hi, uint32_t lo) { const uint32_t y = (hi & 0x80000000u) | (lo & 0x7fffffffu); return (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u); };
+                const uint32_t a0 = ring[nn & (kMtRing - 1u)], a1 = ring[(nn + 1u) & (kMtRing - 1u)], am = ring[(nn + 397u) & (kMtRing - 1u)];
+                const uint32_t b0 = ring[(nn + 227u) & (kMtRing - 1u)], b1 = ring[(nn + 228u) & (kMtRing - 1u)];
+                const uint32_t w1 = am ^ twist(a0, a1), w2 = w1 ^ twist(b0, b1);
+                ring[(nn + 624u) & (kMtRing - 1u)] = w1;
+                ring[(nn + 851u) & (kMtRing - 1u)] = w2;
+                if (t < kMtThird) {                             // and a third one while y[nn + 455] is still an old word: t + 455 < 624
+                    const uint32_t c0 = ring[(nn + 454u) & (kMtRing - 1u)], c1 = ring[(nn + 455u) & (kMtRing - 1u)];
+                    ring[(nn + 1078u) & (kMtRing - 1u)] = w2 ^ twist(c0, c1);
+                }
             }
-            have += kMtStep;
+            have += 2u * kMtStep + kMtThird;                    // 623 words per barrier
             __syncthreads();
         }
         // ---- two paths per thread: local indices l and l + 256 ----
