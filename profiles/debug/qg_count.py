@@ -1,3 +1,8 @@
+#!/usr/bin/env python3
+"""Traced-segment counter of one frame by four routes: the oracle, the sample-queue kernel's grid form, the nested item walk
+(APT_GRID_WALK=items) and the brute-force traversal over LDS tiles, for sample counts with and without an n % 8 tail.  (Found in
+round 3: with a tail the frame kernels counted the re-traced first tail sample of the lanes past the tail; fixed in pt_kernels.h.)
+    python profiles/debug/qg_count.py"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
