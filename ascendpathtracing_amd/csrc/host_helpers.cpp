@@ -231,7 +231,7 @@ int apt_gen_scene_host(uint32_t num_spheres, uint64_t seed, float *spheres, size
 // they go to an always-tested list; the others are binned by their bounding boxes, inflated by `margin`
 // so that any ray the fp32 intersection formula can possibly accept passes through the interior of a
 // cell that lists the sphere (the formula's absolute error on disc is ~1e-3 at these coordinates; the
-// margin is 0.05 + 1e-4 * coordinate scale).  Cells are sized for ~1 sphere centre each (APT_GRID_SPHERES_PER_CELL overrides: tuning knob).
+// margin is 0.05 + 1e-4 * coordinate scale).  Cells are sized for kGridSpheresPerCell = 0.5 sphere centres each (APT_GRID_SPHERES_PER_CELL overrides: tuning knob).
 int apt_build_grid_host(const float *sph, uint32_t ns, void *grid, size_t *out_bytes) {
     apt::clear_error();
     if (!sph || ns == 0 || !out_bytes) return set_error(APT_ERR_ARG, "apt_build_grid_host: spheres/out_bytes must be non-null, num_spheres non-zero%s");
@@ -249,7 +249,10 @@ int apt_build_grid_host(const float *sph, uint32_t ns, void *grid, size_t *out_b
         const float c[3] = {cx[k], cy[k], cz[k]};
         for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], c[a] - rad[k]); hi[a] = std::max(hi[a], c[a] + rad[k]); scale = std::max(scale, std::fabs(c[a]) + rad[k]); }
     }
-    double per_cell = 1.0; // sphere centres per cell (boxes overlap ~4 cells each); measured 74.4 / 70.7 / 70.3 / 70.8 / 72.2 ms at 2 / 1 / 0.7 / 0.5 / 0.35
+    // sphere centres per cell (boxes overlap ~4 cells each).  The nested walk (round 1, 64 spp): 74.4 / 70.7 / 70.3 / 70.8 / 72.2 ms at 2 / 1 / 0.7 /
+    // 0.5 / 0.35; the sample-queue kernel's grid form (round 3): 66.8 / 60.1 / 58.8 / 58.4 / 59.0 / 60.5 / 63.6 ms at 2 / 1 / 0.7 / 0.5 / 0.35 / 0.25 /
+    // 0.18 -- a cell step is cheaper there than a pair slot, so smaller cells pay a little longer.
+    double per_cell = apt::kGridSpheresPerCell;
     if (const char *e = getenv("APT_GRID_SPHERES_PER_CELL")) { const double v = atof(e); if (v > 0.01 && v < 1e6) per_cell = v; }
     apt::GridHeader h;
     apt::grid_header_from_stats(ns, (uint32_t)small.size(), (uint32_t)large.size(), lo, hi, scale, per_cell, h);

@@ -630,6 +630,7 @@ constexpr uint32_t kGridSlotCountBits = 6;       // cellslot: low bits = slots o
 constexpr uint32_t kGridSlotCountMax = (1u << kGridSlotCountBits) - 1u;
 constexpr uint32_t kGridNoSphere = 0xffffffffu;  // id of a pad
 constexpr uint32_t kGridMagic = 0x47524944u; // "GRID"
+constexpr double kGridSpheresPerCell = 0.5;     // default cell size of both builders: sphere centres per cell (APT_GRID_SPHERES_PER_CELL overrides)
 constexpr uint32_t kGridMaxCellsPerAxis = 512;  // round 1 capped the grid at 128 cells per axis
 
 // The header of the grid from the statistics of the scene's small spheres (host arithmetic, shared by apt_build_grid_host

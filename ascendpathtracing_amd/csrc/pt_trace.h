@@ -745,8 +745,25 @@ __device__ __forceinline__ void grid_segment(const GridCtx &ctx, PathState &s, b
         const float t = select_root(hp.b - q, hp.b + q, ta.eps);
         if (t < tmin || (t == tmin && (int)k < idx)) { tmin = t; idx = (int)k; }
     };
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(APT_GRID_HEADER_VMEM)
+    if (grid_ok && h.off_cellslot) {
+        // The always-tested list from its pair slots, by explicit SCALAR loads (wave-uniform data the compiler would fetch with vector
+        // loads and a wait each, like the header: load_grid_header): two spheres and their ids per pair of loads.
+        typedef float f32x8 __attribute__((ext_vector_type(8)));
+        typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+        const float *sg = reinterpret_cast<const float *>(grid + h.off_slots);
+        const uint32_t *si = grid + h.off_slot_ids;
+        for (uint32_t j = 0; j < h.slot_base; ++j) {
+            f32x8 g8;
+            u32x2 id2;
+            asm volatile("s_load_dwordx8 %0, %2, 0x0\n\ts_load_dwordx2 %1, %3, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(g8), "=&s"(id2) : "s"(sg + 8 * j), "s"(si + 2 * j) : "memory");
+            test_large(make_float4(g8[0], g8[2], g8[4], g8[6]), id2[0]);
+            if (id2[1] != kGridNoSphere) test_large(make_float4(g8[1], g8[3], g8[5], g8[7]), id2[1]);
+        }
+    } else
+#endif
     if (grid_ok)
-        for (uint32_t i = 0; i < h.nlarge; ++i) { const uint32_t k = large[i]; test_large(geom[k], k); } // wave-uniform: scalar loads
+        for (uint32_t i = 0; i < h.nlarge; ++i) { const uint32_t k = large[i]; test_large(geom[k], k); } // wave-uniform
     const float dd = s.dxy.x * s.dxy.x + s.dxy.y * s.dxy.y + s.dz * s.dz;
     const bool unit = fabsf(dd - 1.0f) <= 1e-3f; // false for NaN/inf
     if (!grid_ok) {
@@ -860,10 +877,34 @@ __device__ __forceinline__ bool grid_queue_usable(const TraceArgs &ta) {
     return h && h->magic == kGridMagic && h->num_spheres == ta.ns && h->off_cellslot != 0 && eps_allows_rootkey(ta.eps);
 }
 
+// The 128-byte header by two SCALAR loads: it is wave-uniform, but the compiler cannot prove that the kernel's own stores never
+// touch the grid buffer and would fetch every field with a vector load (and a wait) at each use.
+__device__ __forceinline__ GridHeader load_grid_header(const uint32_t *grid) {
+    static_assert(sizeof(GridHeader) == 128, "two s_load_dwordx16");
+    GridHeader h;
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
+    u32x16 w0, w1;
+    asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx16 %1, %2, 0x40\n\ts_waitcnt lgkmcnt(0)" : "=&s"(w0), "=&s"(w1) : "s"(grid) : "memory");
+    uint32_t hw[32];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { hw[i] = w0[i]; hw[16 + i] = w1[i]; }
+    __builtin_memcpy(&h, hw, sizeof h);
+#else
+    __builtin_memcpy(&h, grid, sizeof h);
+#endif
+    return h;
+}
+
 template <int MODE, bool RETIRE>
 __device__ __forceinline__ uint32_t trace_grid(const float *__restrict__ sph, const uint32_t *__restrict__ grid,
                                                PathState &s, bool valid, const TraceArgs &ta, uint64_t path) {
+#ifdef APT_GRID_HEADER_VMEM
     const GridCtx gc{reinterpret_cast<const GridHeader *>(grid), sph, grid, &ta};
+#else
+    const GridHeader hdr = load_grid_header(grid);
+    const GridCtx gc{&hdr, sph, grid, &ta};
+#endif
     const uint64_t rr_key = ta.rr_start ? rr_path_key(ta.seed, path) : 0;
     uint32_t traced = 0, n_cells = 0, n_tests = 0; // statistics
     for (uint32_t d = 0; d < ta.depth; ++d) {

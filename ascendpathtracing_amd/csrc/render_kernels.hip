@@ -522,7 +522,7 @@ int apt_build_grid_device(const float *spheres_dev, uint32_t ns, void *stream, v
         if (e == hipSuccess) e = hipStreamSynchronize(st);
     }
     if (e == hipSuccess) {
-        double per_cell = 1.0;
+        double per_cell = kGridSpheresPerCell;
         if (const char *env = getenv("APT_GRID_SPHERES_PER_CELL")) { const double v = atof(env); if (v > 0.01 && v < 1e6) per_cell = v; }
         grid_header_from_stats(ns, stt.nsmall, stt.nlarge, stt.lo, stt.hi, stt.scale, per_cell, h);
         const uint64_t nc1 = (uint64_t)h.ncells + 1, nblk = (nc1 + kGB - 1) / kGB;
