@@ -478,7 +478,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SC == kScene
             bool stop = false;                                  // (wave masks are only updated outside divergent regions)
             const bool w = lane_in(walking);
             const bool need = w && cur >= end;                  // list exhausted: leave the cell
-            if (__builtin_amdgcn_ballot_w64(need) != 0) {
+            {
                 if (need) {
                     const float te = fminf(tm0, fminf(tm1, tm2));                   // parameter at which the ray leaves this cell
                     const float tmin = bits_f32(bestk + kbias);
@@ -501,7 +501,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SC == kScene
                 }
             }
             const bool has = w && !stop && cur < end;
-            if (__builtin_amdgcn_ballot_w64(has) != 0) {
+            {
                 if (has) {
                     const float4 a = slot_geom[cur], c4 = slot_geom[cur + 1u];   // slot cur / 2: float4s 2 * slot and 2 * slot + 1
                     test_pair(a, c4, cur, std::true_type{});
@@ -618,9 +618,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SC == kScene
                             int ci = (int)floorf((o + dv * tn - lo) * invw);
                             ci = ci < 0 ? 0 : (ci >= na ? na - 1 : ci);
                             c = ci;
-                            if (dv > 1e-20f) { inc = stride; steps = (uint32_t)(na - 1 - ci); tmax = (lo + (float)(ci + 1) * cellw - o) * inv; tdel = cellw * inv; }
-                            else if (dv < -1e-20f) { inc = -stride; steps = (uint32_t)ci; tmax = (lo + (float)ci * cellw - o) * inv; tdel = -cellw * inv; }
-                            else { inc = 0; steps = 0; tmax = 3.0e38f; tdel = 3.0e38f; }   // never the nearest crossing of a unit direction within kMissT
+                            // one form for both directions: the boundary ahead is plane ci + 1 (dv > 0) or ci (dv < 0), and -cellw * inv = cellw * |inv|
+                            const bool fwd = dv > 0.0f, moves = fabsf(dv) > 1e-20f;
+                            const float t_b = (lo + (float)(ci + (fwd ? 1 : 0)) * cellw - o) * inv;
+                            tmax = moves ? t_b : 3.0e38f;                     // (an axis that does not move is never the nearest crossing of a unit
+                            tdel = moves ? cellw * fabsf(inv) : 3.0e38f;      //  direction within kMissT)
+                            inc = moves ? (fwd ? stride : -stride) : 0;
+                            steps = moves ? (uint32_t)(fwd ? na - 1 - ci : ci) : 0u;
                         };
                         int c0, c1, c2;
                         uint32_t l0, l1, l2;
@@ -672,6 +676,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SC == kScene
             atomicAdd(ta.traced + 2, 64ull * n_gen_exec);
         }
         if (n_exact) atomicAdd(ta.traced + 3, (unsigned long long)n_exact);
+#ifdef APT_GRID_DEBUG_STATS   // measurement build only: lane-slots of the per-segment block in the "exact re-runs" slot
+        if (SC == kSceneGrid) atomicAdd(ta.traced + 3, 64ull * n_bounce_exec);
+#endif
     }
 }
 
