@@ -261,7 +261,7 @@ int apt_build_grid_host(const float *sph, uint32_t ns, void *grid, size_t *out_b
         uint32_t x0, x1, y0, y1, z0, z1;
         apt::grid_cell_range(h, cx[k], rad[k], 0, x0, x1); apt::grid_cell_range(h, cy[k], rad[k], 1, y0, y1); apt::grid_cell_range(h, cz[k], rad[k], 2, z0, z1);
         for (uint32_t z = z0; z <= z1; ++z) for (uint32_t y = y0; y <= y1; ++y) for (uint32_t x = x0; x <= x1; ++x)
-            ++count[(z * h.n[1] + y) * h.n[0] + x + 1];
+            if (apt::grid_cell_touches(h, cx[k], cy[k], cz[k], rad[k], x, y, z)) ++count[(z * h.n[1] + y) * h.n[0] + x + 1];
     }
     for (uint32_t c = 0; c < h.ncells; ++c) count[c + 1] += count[c];
     const size_t words = apt::grid_header_offsets(h, count[h.ncells]);
@@ -277,7 +277,7 @@ int apt_build_grid_host(const float *sph, uint32_t ns, void *grid, size_t *out_b
         uint32_t x0, x1, y0, y1, z0, z1;
         apt::grid_cell_range(h, cx[k], rad[k], 0, x0, x1); apt::grid_cell_range(h, cy[k], rad[k], 1, y0, y1); apt::grid_cell_range(h, cz[k], rad[k], 2, z0, z1);
         for (uint32_t z = z0; z <= z1; ++z) for (uint32_t y = y0; y <= y1; ++y) for (uint32_t x = x0; x <= x1; ++x)
-            w[h.off_items + cursor[(z * h.n[1] + y) * h.n[0] + x]++] = k;
+            if (apt::grid_cell_touches(h, cx[k], cy[k], cz[k], rad[k], x, y, z)) w[h.off_items + cursor[(z * h.n[1] + y) * h.n[0] + x]++] = k;
     }
     float *g = (float *)(w + h.off_geom);
     for (uint32_t k = 0; k < ns; ++k) { g[4 * k] = cx[k]; g[4 * k + 1] = cy[k]; g[4 * k + 2] = cz[k]; g[4 * k + 3] = r2[k]; }

@@ -719,6 +719,23 @@ APT_HD void grid_cell_range(const GridHeader &h, float c, float rad, int a, uint
     c0 = (uint32_t)(f0 < 0.0 ? 0.0 : (f0 > hi ? hi : f0));   // NaN never reaches here: non-finite spheres are "large"
     c1 = (uint32_t)(f1 < 0.0 ? 0.0 : (f1 > hi ? hi : f1));
 }
+// Does the small sphere (centre, rad), inflated by the margin, touch cell (x, y, z)?  Squared distance from the centre to the cell's box against
+// (rad + margin)^2, with a relative slack so that rounding can only KEEP a cell.  The box test of grid_cell_range lists a sphere in the corner
+// cells of its bounding box too; a ray can only be accepted by the sphere at a point within rad (1 + fp error) of the centre, and that point
+// lies in a cell whose box is at most that far from the centre, so corner cells beyond rad + margin can never matter (same argument, same
+// margin, as for the box).  Same operations on host and device (no contraction): both builders make the same lists.
+APT_HD bool grid_cell_touches(const GridHeader &h, float cx, float cy, float cz, float rad, uint32_t x, uint32_t y, uint32_t z) {
+    const float c[3] = {cx, cy, cz};
+    const uint32_t idx[3] = {x, y, z};
+    float d2 = 0.0f;
+    for (int a = 0; a < 3; ++a) {
+        const float lo = h.gmin[a] + (float)idx[a] * h.cell[a], hi = h.gmin[a] + (float)(idx[a] + 1u) * h.cell[a];
+        const float d = c[a] < lo ? lo - c[a] : (c[a] > hi ? c[a] - hi : 0.0f);
+        d2 = d2 + d * d;
+    }
+    const float R = rad + h.margin;
+    return d2 <= R * R * 1.001f;
+}
 // classification key of a radius: non-finite radii sort last, so that the median (and with it the small / large split) is
 // defined for every scene and the same on host and device
 APT_HD float grid_radius(float r2) {

@@ -124,8 +124,9 @@ __global__ __launch_bounds__(256) void grid_count_kernel(GridHeader h, const flo
     grid_cell_range(h, sph[ns + k], rad[k], 0, x0, x1);
     grid_cell_range(h, sph[2 * (size_t)ns + k], rad[k], 1, y0, y1);
     grid_cell_range(h, sph[3 * (size_t)ns + k], rad[k], 2, z0, z1);
+    const float cx = sph[ns + k], cy = sph[2 * (size_t)ns + k], cz = sph[3 * (size_t)ns + k];
     for (uint32_t z = z0; z <= z1; ++z) for (uint32_t y = y0; y <= y1; ++y) for (uint32_t x = x0; x <= x1; ++x)
-        atomicAdd(&count[(z * h.n[1] + y) * h.n[0] + x + 1], 1u);
+        if (grid_cell_touches(h, cx, cy, cz, rad[k], x, y, z)) atomicAdd(&count[(z * h.n[1] + y) * h.n[0] + x + 1], 1u);
 }
 
 // exclusive scan in place over n words: per-block sums, a one-block scan of the sums, add-back (three launches)
@@ -181,7 +182,9 @@ __global__ __launch_bounds__(256) void grid_fill_kernel(GridHeader h, const floa
     grid_cell_range(h, sph[ns + k], rad[k], 0, x0, x1);
     grid_cell_range(h, sph[2 * (size_t)ns + k], rad[k], 1, y0, y1);
     grid_cell_range(h, sph[3 * (size_t)ns + k], rad[k], 2, z0, z1);
+    const float cx = sph[ns + k], cy = sph[2 * (size_t)ns + k], cz = sph[3 * (size_t)ns + k];
     for (uint32_t z = z0; z <= z1; ++z) for (uint32_t y = y0; y <= y1; ++y) for (uint32_t x = x0; x <= x1; ++x) {
+        if (!grid_cell_touches(h, cx, cy, cz, rad[k], x, y, z)) continue;
         const uint32_t c = (z * h.n[1] + y) * h.n[0] + x;
         items[cell_start[c] + atomicAdd(&cursor[c], 1u)] = k;
     }

@@ -106,7 +106,7 @@ def test_compute_entries_fail_loudly_without_a_gpu(apt):
 
 def test_grid_builder_layout(apt):
     """apt_build_grid_host: header, always-tested list (walls + light), every small sphere listed in every
-    cell its inflated box touches, ascending sphere order inside a cell."""
+    cell its inflated sphere touches (checked per cell against the definition), ascending sphere order inside a cell."""
     ns = 500
     scene = apt.gen_data.gen_scene(ns, seed=4)
     g = apt.gen_data.build_grid(scene, ns)
@@ -123,6 +123,22 @@ def test_grid_builder_layout(apt):
         lst = items[starts[c]:starts[c + 1]]
         assert (np.diff(lst.astype(np.int64)) > 0).all()
     assert set(items.tolist()) == set(range(6, ns - 1))
+    # the lists against their definition: sphere k is in cell c iff the box of c is within rad + margin of the centre (pt_core.h grid_cell_touches)
+    fl = g[13:26].view(np.float32)
+    gmin, cellw, margin = fl[0:3].astype(np.float64), fl[6:9].astype(np.float64), float(fl[12])
+    tab64 = scene[:10 * ns].reshape(10, ns).astype(np.float64)
+    for c in range(0, ncells, max(1, ncells // 40)):
+        z, rem_ = divmod(c, int(n[0]) * int(n[1])); y, x = divmod(rem_, int(n[0]))
+        lo = gmin + np.array([x, y, z]) * cellw
+        hi = lo + cellw
+        ctr = tab64[1:4, 6:ns - 1]
+        d = np.maximum(np.maximum(lo[:, None] - ctr, ctr - hi[:, None]), 0.0)
+        dist = np.sqrt((d * d).sum(axis=0))
+        reach = np.sqrt(tab64[0, 6:ns - 1]) + margin
+        listed = set(items[starts[c]:starts[c + 1]].tolist())
+        must = set((np.nonzero(dist <= reach * 0.999)[0] + 6).tolist())      # clearly touching: must be listed
+        may = set((np.nonzero(dist <= reach * 1.01)[0] + 6).tolist())        # clearly apart: must not be
+        assert must <= listed <= may, (c, sorted(must - listed), sorted(listed - may))
     geom = g[off_geom:off_geom + 4 * ns].view(np.float32).reshape(ns, 4)
     tab = scene[:10 * ns].reshape(10, ns)
     assert np.array_equal(geom[:, 0], tab[1]) and np.array_equal(geom[:, 3], tab[0])
