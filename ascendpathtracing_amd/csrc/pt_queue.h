@@ -593,7 +593,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SC == kScene
                 } else {
                     for (uint32_t j = 0; j < h.slot_base; ++j) {    // the always-tested list: wave-uniform addresses, scalar loads
                         f32x8 g8;
-                        asm volatile("s_load_dwordx8 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(g8) : "s"(slot_geom + 2 * j) : "memory");
+                        asm volatile("s_load_dwordx8 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(g8) : "s"(slot_geom + 2 * j) : "memory");
                         test_pair(make_float4(g8[0], g8[1], g8[2], g8[3]), make_float4(g8[4], g8[5], g8[6], g8[7]), 2 * j, std::false_type{});
                         n_tests += 2;
                     }
