@@ -323,34 +323,64 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SC == kScene
         }
     };
     // One bounce of the wave, in place.  Idle lanes compute on stale state: whatever they hold is overwritten when they take
-    // their next ray.  When a lane whose path can still reach an output leaves the validity range of the fast sequences
-    // (about 1e-5 of the wave-bounces), the bounce is redone for the whole wave with sqrtf() and '/' in a cold block.
+    // their next ray.  The bounce runs in two phases (pt_trace.h bounce_ns8_v2_hit / _reflect): whether a lane whose path can still
+    // reach an output left the validity range of the fast sequences (about 1e-5 of the wave-bounces) is known BEFORE the new ray
+    // is written, so the exact form (sqrtf() and '/', a cold block) still finds the old ray in the state registers and the fast form
+    // writes the new ray over them (fewer live registers and copies: C2 with retirement 16.69 -> 16.33 ms, depth 32 35.2 -> 34.4).
     auto step = [&](PathState &st, auto planes_tag) __attribute__((always_inline)) {
         constexpr bool PLANES = decltype(planes_tag)::value;
-        PathState nx;
-        Albedo albedo;
-        uint64_t alive_out = alive;
-        bool redo_any = !fast_ok;
-        if (__builtin_expect(fast_ok, 1)) {
-            const uint64_t redo = bounce_ns8_v2<MODE, PLANES>(sc, tab8, st, nx, ta, kc, alive_out, albedo) & active;
-            if (__builtin_expect(redo != 0, 0)) { // a finished path's request is ignored (trace_ns8)
-                const bool fin = select_const(alive, 1) == 0 || (thr_xy.x == 0.0f && thr_xy.y == 0.0f && thr_z == 0.0f);
-                redo_any = __builtin_amdgcn_ballot_w64(select_const(redo, 1) != 0 && !fin) != 0; // (ballot: uniform for the compiler, __any is not)
+        // (With roulette the one-block form stays: its key and draw need the registers the two-phase form would spill -- 15.35 against 15.45 ms.)
+        if (RR) {
+            PathState nx;
+            Albedo albedo;
+            uint64_t alive_out = alive;
+            bool redo_any = !fast_ok;
+            if (__builtin_expect(fast_ok, 1)) {
+                const uint64_t redo = bounce_ns8_v2<MODE, PLANES>(sc, tab8, st, nx, ta, kc, alive_out, albedo) & active;
+                if (__builtin_expect(redo != 0, 0)) { // a finished path's request is ignored (trace_ns8)
+                    const bool fin = select_const(alive, 1) == 0 || (thr_xy.x == 0.0f && thr_xy.y == 0.0f && thr_z == 0.0f);
+                    redo_any = __builtin_amdgcn_ballot_w64(select_const(redo, 1) != 0 && !fin) != 0; // (ballot: uniform for the compiler, __any is not)
+                }
+            }
+            if (__builtin_expect(redo_any, 0)) {
+                ++n_exact;
+                PathState c = st, o;
+                c.rxy = thr_xy; c.rz = thr_z; c.alive = select_const(alive, 1);
+                (void)bounce_ns8<MODE, false>(sc, tab8, c, o, ta);
+                nx.oxy = o.oxy; nx.oz = o.oz; nx.dxy = o.dxy; nx.dz = o.dz;
+                thr_xy = o.rxy; thr_z = o.rz;
+                alive = __builtin_amdgcn_ballot_w64(o.alive != 0);
+            } else {
+                apply_albedo(thr_xy, thr_z, albedo, alive_out);
+                alive = alive_out;
+            }
+            st.oxy = nx.oxy; st.oz = nx.oz; st.dxy = nx.dxy; st.dz = nx.dz;
+        } else {
+            Bounce8Mid mid;
+            bool redo_any = !fast_ok;
+            if (__builtin_expect(fast_ok, 1)) {
+                const uint64_t redo = bounce_ns8_v2_hit<MODE, PLANES>(sc, tab8, st, ta, kc, mid) & active;
+                if (__builtin_expect(redo != 0, 0)) { // a finished path's request is ignored (trace_ns8)
+                    const bool fin = select_const(alive, 1) == 0 || (thr_xy.x == 0.0f && thr_xy.y == 0.0f && thr_z == 0.0f);
+                    redo_any = __builtin_amdgcn_ballot_w64(select_const(redo, 1) != 0 && !fin) != 0; // (ballot: uniform for the compiler, __any is not)
+                }
+            }
+            if (__builtin_expect(redo_any, 0)) {
+                ++n_exact;
+                PathState c = st, o;
+                c.rxy = thr_xy; c.rz = thr_z; c.alive = select_const(alive, 1);
+                (void)bounce_ns8<MODE, false>(sc, tab8, c, o, ta);
+                st.oxy = o.oxy; st.oz = o.oz; st.dxy = o.dxy; st.dz = o.dz;
+                thr_xy = o.rxy; thr_z = o.rz;
+                alive = __builtin_amdgcn_ballot_w64(o.alive != 0);
+            } else {
+                Albedo albedo;
+                uint64_t alive_out = alive;
+                bounce_ns8_v2_reflect<MODE>(st, mid, alive_out, albedo);
+                apply_albedo(thr_xy, thr_z, albedo, alive_out);
+                alive = alive_out;
             }
         }
-        if (__builtin_expect(redo_any, 0)) {
-            ++n_exact;
-            PathState c = st, o;
-            c.rxy = thr_xy; c.rz = thr_z; c.alive = select_const(alive, 1);
-            (void)bounce_ns8<MODE, false>(sc, tab8, c, o, ta);
-            nx.oxy = o.oxy; nx.oz = o.oz; nx.dxy = o.dxy; nx.dz = o.dz;
-            thr_xy = o.rxy; thr_z = o.rz;
-            alive = __builtin_amdgcn_ballot_w64(o.alive != 0);
-        } else {
-            apply_albedo(thr_xy, thr_z, albedo, alive_out);
-            alive = alive_out;
-        }
-        st.oxy = nx.oxy; st.oz = nx.oz; st.dxy = nx.dxy; st.dz = nx.dz;
         post_bounce();
     };
 

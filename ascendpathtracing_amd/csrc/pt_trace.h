@@ -450,6 +450,79 @@ __device__ __forceinline__ uint64_t bounce_ns8_v2(const Scene8 &sc, const Tab8 t
     return __builtin_amdgcn_ballot_w64(!(amin >= kFastMin)); // something too small, len2 > 2^60, or a NaN
 }
 
+// bounce_ns8_v2 in TWO phases, for a loop that keeps ONE set of state registers (pt_queue.h): everything the validity test of the
+// fast sequences needs is known after the hit point, the normal and rsq(|normal|^2) -- BEFORE anything of the new ray is written.
+// A caller that branches to its exact form between the phases still holds the untouched ray there, and on the fast path the new ray
+// can be written over the old one (its last reads are the instructions that produce the new values): no copies at the back edge.
+// Same operations in the same order as bounce_ns8_v2.
+struct Bounce8Mid {            // what phase 2 needs from phase 1
+    f2 hxy, nxy;
+    float hz, nz, len2, r0;
+    float4 col;
+    uint64_t light;
+};
+template <int MODE, bool PLANES>
+__device__ __forceinline__ uint64_t bounce_ns8_v2_hit(const Scene8 &sc, const Tab8 tab, const PathState &s, const TraceArgs &ta, const KeyConsts &kc,
+                                                      Bounce8Mid &m) {
+    float amin = 1.0f;
+    const Hit8 hit = intersect_ns8_v2<MODE, PLANES>(sc, s.oxy.x, s.oxy.y, s.oz, s.dxy.x, s.dxy.y, s.dz, ta, kc, amin);
+    const float tmin = hit.tmin;
+    const float4 c = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(tab.geo) + hit.addr);
+    m.col = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(tab.alb) + hit.addr);
+    m.light = hit.light;
+    m.hxy = s.oxy + s.dxy * tmin;                             // :513-518  h = o + d*t (mul, then add)
+    m.hz = s.oz + s.dz * tmin;
+    m.nxy = m.hxy - f2{c.x, c.y};                              // :635-637
+    m.nz = m.hz - c.z;
+    const f2 sq = m.nxy * m.nxy;
+    if (MODE == kModeOracle) {                                 // np.linalg.norm, gen_data.py:347: float64 accumulation
+        const float p2 = m.nz * m.nz;
+        double acc = 0.0 + (double)sq.x;
+        acc = acc + (double)sq.y;
+        acc = acc + (double)p2;
+        m.len2 = (float)acc;
+    } else {
+        float acc = sq.x + sq.y;                               // :641-649 (0 + x^2 is x^2: a square is never -0)
+        acc = acc + m.nz * m.nz;
+        m.len2 = acc;
+    }
+    m.r0 = __builtin_amdgcn_rsqf(m.len2);
+    amin = minimum3_abs_after_trans(amin, m.r0, m.nxy.x);      // validity of the fast sqrt / divide sequences: see kFastMin
+    amin = minimum3_abs(amin, m.nxy.y, m.nz);
+    return __builtin_amdgcn_ballot_w64(!(amin >= kFastMin));   // something too small, len2 > 2^60, or a NaN
+}
+template <int MODE>
+__device__ __forceinline__ void bounce_ns8_v2_reflect(PathState &s, const Bounce8Mid &m, uint64_t &alive, Albedo &albedo) {
+    float L;
+    {
+        const float y = m.len2 * m.r0, h = 0.5f * m.r0;
+        const float r = __builtin_fmaf(-y, y, m.len2);
+        L = __builtin_fmaf(r, h, y);
+    }
+    f2 uxy;
+    float uz;
+    div3_packed(m.nxy, m.nz, L, uxy, uz);
+    const f2 pr = s.dxy * uxy;
+    const float pz = s.dz * uz;
+    float dot;
+    if (MODE == kModeOracle) {                                 // np.dot, gen_data.py:349
+        double acc = 0.0 + (double)pr.x;
+        acc = acc + (double)pr.y;
+        acc = acc + (double)pz;
+        dot = (float)acc;
+    } else {
+        dot = 0.0f + pr.x;                                     // :690 Duplicate(0), :694-696
+        dot = dot + pr.y;
+        dot = dot + pz;
+    }
+    const float k2 = dot * 2.0f;                               // :697
+    s.dxy = s.dxy - uxy * k2;                                  // :699-704
+    s.dz = s.dz - uz * k2;
+    s.oxy = m.hxy; s.oz = m.hz;                                // :706-708
+    alive &= ~m.light;
+    albedo = Albedo{f2{m.col.x, m.col.y}, m.col.z};
+}
+
 // The same with the plane-sharing form of the intersections chosen at run time (scene8_shares_planes(), wave-uniform)
 template <int MODE>
 __device__ __forceinline__ uint64_t bounce_ns8_v2p(const Scene8 &sc, const Tab8 tab, const PathState &s, PathState &n, const TraceArgs &ta,
