@@ -404,6 +404,48 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SC == kScene
     // so that a logic error can never leave a wave spinning on the GPU.
     uint32_t guard = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)min(4ull * ((uint64_t)npx * 4u * S * ((uint64_t)ta.depth + 1u) + 64u), 0xffffffffull));
     auto run = [&](auto planes_tag) __attribute__((always_inline)) {
+#ifndef APT_QUEUE_JOIN_LOOP
+        if (!RR) {
+            // The hot loop holds the FAST form only and leaves through an exit taken before anything of the new ray is written (phase 1
+            // of the bounce decides): no join of a fast and an exact arm inside the loop, so the register allocator keeps the new ray in
+            // the state registers.  The exact form (cold) runs between two visits of the hot loop.
+            constexpr bool PLANES = decltype(planes_tag)::value;
+            bool finished = false;
+            while (!finished) {
+                bool need_exact = false;
+                for (;;) {
+                    if (service(s) || guard-- == 0u) { finished = true; break; }
+                    Bounce8Mid mid;
+                    bool redo_any = !fast_ok;
+                    if (__builtin_expect(fast_ok, 1)) {
+                        const uint64_t redo = bounce_ns8_v2_hit<MODE, PLANES>(sc, tab8, s, ta, kc, mid) & active;
+                        if (__builtin_expect(redo != 0, 0)) { // a finished path's request is ignored (trace_ns8)
+                            const bool fin = select_const(alive, 1) == 0 || (thr_xy.x == 0.0f && thr_xy.y == 0.0f && thr_z == 0.0f);
+                            redo_any = __builtin_amdgcn_ballot_w64(select_const(redo, 1) != 0 && !fin) != 0;
+                        }
+                    }
+                    if (__builtin_expect(redo_any, 0)) { need_exact = true; break; }
+                    Albedo albedo;
+                    uint64_t alive_out = alive;
+                    bounce_ns8_v2_reflect<MODE>(s, mid, alive_out, albedo);
+                    apply_albedo(thr_xy, thr_z, albedo, alive_out);
+                    alive = alive_out;
+                    post_bounce();
+                }
+                if (need_exact) {
+                    ++n_exact;
+                    PathState c = s, o;
+                    c.rxy = thr_xy; c.rz = thr_z; c.alive = select_const(alive, 1);
+                    (void)bounce_ns8<MODE, false>(sc, tab8, c, o, ta);
+                    s.oxy = o.oxy; s.oz = o.oz; s.dxy = o.dxy; s.dz = o.dz;
+                    thr_xy = o.rxy; thr_z = o.rz;
+                    alive = __builtin_amdgcn_ballot_w64(o.alive != 0);
+                    post_bounce();
+                }
+            }
+            return;
+        }
+#endif
         for (;;) {
             if (service(s) || guard-- == 0u) break;
             step(s, planes_tag);
@@ -421,8 +463,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SC == kScene
     // keys) -- or, its list exhausted, leaves the cell (exit test, one DDA step, ONE dword with the next cell's slot range).  A lane
     // whose walk has ended waits; as soon as `refill_lanes` lanes wait (or nobody walks) the per-segment block runs for all of them
     // together: shading step, roulette, park / refill from the ray pool, always-tested spheres, slab test, DDA set-up.
-    // The arg-min is a 64-bit (root key, sphere id) minimum: on equal t the lower sphere index wins, as in the reference's strict
-    // '<' loop over ascending indices, with no tie bookkeeping (a sphere met again in the next cell yields the same pair).
+    // The arg-min carries (root key, position of the candidate): equal keys inside a list resolve by order (ids ascend there); a tie
+    // with the minimum of an earlier list is recorded and settled by the two sphere ids when the segment is shaded (test_pair below).
     // Exactness: operation for operation intersect_pre / correctly rounded square root / select_root; a discriminant outside the
     // fast square root's range (|disc| < 2^-96) is redone with sqrtf() on the spot.  Lanes whose direction is not of unit length
     // test every sphere (trace_grid's rule).  The frame is bit-identical to render_frame_kernel's (tests/test_gpu_parity.py).
