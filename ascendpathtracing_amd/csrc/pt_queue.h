@@ -327,9 +327,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SC == kScene
     // reach an output left the validity range of the fast sequences (about 1e-5 of the wave-bounces) is known BEFORE the new ray
     // is written, so the exact form (sqrtf() and '/', a cold block) still finds the old ray in the state registers and the fast form
     // writes the new ray over them (fewer live registers and copies: C2 with retirement 16.69 -> 16.33 ms, depth 32 35.2 -> 34.4).
+#ifdef APT_QUEUE_JOIN_LOOP
     auto step = [&](PathState &st, auto planes_tag) __attribute__((always_inline)) {
         constexpr bool PLANES = decltype(planes_tag)::value;
-        // (With roulette the one-block form stays: its key and draw need the registers the two-phase form would spill -- 15.35 against 15.45 ms.)
+        // (Only used by the measurement form of run() below, -DAPT_QUEUE_JOIN_LOOP; with roulette it keeps the one-block bounce, which that
+        // form ran faster: 15.35 against 15.45 ms.)
         if (RR) {
             PathState nx;
             Albedo albedo;
@@ -383,6 +385,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SC == kScene
         }
         post_bounce();
     };
+#endif
 
     // Service between two bounces: park, refill from what the pool holds; when the pool has room for a batch, (sum the oldest
     // unit if its buffer is needed,) generate 64 rays and refill again, so that a lane never idles because the pool ran dry.
@@ -405,7 +408,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SC == kScene
     uint32_t guard = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)min(4ull * ((uint64_t)npx * 4u * S * ((uint64_t)ta.depth + 1u) + 64u), 0xffffffffull));
     auto run = [&](auto planes_tag) __attribute__((always_inline)) {
 #ifndef APT_QUEUE_JOIN_LOOP
-        if (!RR) {
+        {
             // The hot loop holds the FAST form only and leaves through an exit taken before anything of the new ray is written (phase 1
             // of the bounce decides): no join of a fast and an exact arm inside the loop, so the register allocator keeps the new ray in
             // the state registers.  The exact form (cold) runs between two visits of the hot loop.
@@ -443,13 +446,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SC == kScene
                     post_bounce();
                 }
             }
-            return;
         }
-#endif
+#else   // (measurement: fast and exact arm of the bounce joined inside one loop, step() above)
         for (;;) {
             if (service(s) || guard-- == 0u) break;
             step(s, planes_tag);
         }
+#endif
     };
     // ---- SC == kSceneGrid: any scene through the grid's pair-slot tables, every lane at its own place of its own walk -----------
     // Why this form.  The nested walk of render_frame_kernel (pt_trace.h grid_segment) is bound by the CU's vector-memory ADDRESS
