@@ -13,6 +13,8 @@ APT_FLAG_RETIRE = 1
 APT_FLAG_RR = 2
 APT_FLAG_EMISSION = 4
 APT_FLAG_BAND_BUFFERS = 8
+APT_ERR_DEVICE = 4
+APT_DEV_QUEUE_GUARD, APT_DEV_GRID_TURNS, APT_DEV_LDS_BASE = 1, 2, 4      # bits of the device status word (apt_context_check)
 
 # every symbol include/render_mi355x.h declares
 ABI_SYMBOLS = ["apt_default_params", "render_do", "apt_set_default_params", "render_do_ex", "render_frame",
@@ -23,10 +25,11 @@ ABI_SYMBOLS = ["apt_default_params", "render_do", "apt_set_default_params", "ren
                "apt_context_set_params", "apt_context_set_trace_counter", "apt_context_set_refill_lanes",
                "apt_context_render_do", "apt_context_render_do_ex", "apt_context_render_frame",
                "apt_multi_create", "apt_multi_render", "apt_multi_destroy",
-               "apt_decode_color_band", "apt_mt19937_checkpoints_window", "apt_gen_rays_mt_device_ex", "apt_build_grid_device", "apt_render_frame_mt"]
+               "apt_decode_color_band", "apt_mt19937_checkpoints_window", "apt_gen_rays_mt_device_ex", "apt_build_grid_device", "apt_render_frame_mt",
+               "apt_context_check", "apt_check", "apt_context_set_debug", "apt_set_debug"]
 # the reference declares render_do with C++ linkage (src/main.cpp:9-10): the mangled symbol is exported too
 CXX_RENDER_DO = "_Z9render_dojPvS_PhS0_S0_"
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class AptError(RuntimeError):
@@ -100,7 +103,7 @@ def build_id():
     import hashlib
     csrc = os.path.join(_HERE, "csrc")
     files = sorted(glob.glob(os.path.join(csrc, "*.h")) + glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.cpp")))
-    files += [os.path.join(csrc, "Makefile"), os.path.join(os.path.dirname(_HERE), "include", "render_mi355x.h")]
+    files += [os.path.join(csrc, "Makefile"), os.path.join(csrc, "apt_exports.map"), os.path.join(os.path.dirname(_HERE), "include", "render_mi355x.h")]
     h = hashlib.sha256()
     for f in files:
         h.update(os.path.basename(f).encode() + b"\0")

@@ -40,15 +40,65 @@ apt_context &default_context() {
 }
 } // namespace apt
 
+// The APT_* measurement knobs of the process environment are read HERE, once per context, and nowhere else: no launch path calls
+// getenv() (it races with setenv() in another thread, and a per-context API must not depend on process-global state).
+namespace {
+double env_number(const char *name) {
+    const char *e = getenv(name);
+    return e ? atof(e) : 0.0;
+}
+} // namespace
+
 apt_context::apt_context() {
     apt_default_params(&v_.params);
     v_.trace_counter = nullptr;
     v_.refill_lanes = apt::kDefaultRefillLanes;
+    struct { const char *env, *key; } knobs[] = {{"APT_QUEUE_PPW", "queue_ppw"}, {"APT_QUEUE_NBUF", "queue_nbuf"}, {"APT_QUEUE_LDS_PAD", "queue_lds_pad"},
+                                                 {"APT_GRID_SPHERES_PER_CELL", "grid_spheres_per_cell"}};
+    for (const auto &k : knobs) {
+        const double v = env_number(k.env);
+        if (v != 0.0) (void)set_debug(k.key, v);     // out-of-range values are ignored, as before
+    }
+    if (const char *e = getenv("APT_GRID_WALK")) if (e[0] == 'i') v_.debug.grid_walk = 1;   // "items"
+    apt::clear_error();
 }
 apt_context::Values apt_context::snapshot() { std::lock_guard<std::mutex> g(m_); return v_; }
 void apt_context::set_params(const apt_render_params &p) { std::lock_guard<std::mutex> g(m_); v_.params = p; }
 void apt_context::set_trace_counter(unsigned long long *c) { std::lock_guard<std::mutex> g(m_); v_.trace_counter = c; }
 void apt_context::set_refill_lanes(uint32_t lanes) { std::lock_guard<std::mutex> g(m_); v_.refill_lanes = lanes; }
+int apt_context::set_debug(const char *key, double value) {
+    if (!key) return apt::set_error(APT_ERR_ARG, "apt_context_set_debug: key is null%s");
+    const std::string k(key);
+    const bool whole = value == std::floor(value);
+    std::lock_guard<std::mutex> g(m_);
+    apt::Debug &d = v_.debug;
+    if (k == "queue_ppw") { if (!(whole && value >= 0 && value <= 4096)) goto range; d.queue_ppw = (uint32_t)value; }
+    else if (k == "queue_nbuf") { if (!(whole && (value == 0 || (value >= 2 && value <= 16)))) goto range; d.queue_nbuf = (uint32_t)value; }
+    else if (k == "queue_lds_pad") { if (!(whole && value >= 0 && value <= 32768)) goto range; d.queue_lds_pad = (uint32_t)value; }
+    else if (k == "grid_walk") { if (!(value == 0 || value == 1)) goto range; d.grid_walk = (uint32_t)value; }
+    else if (k == "grid_spheres_per_cell") { if (!(value == 0 || (value > 0.01 && value < 1e6))) goto range; d.grid_spheres_per_cell = value; }
+    else return apt::set_error(APT_ERR_ARG, "apt_context_set_debug: unknown key '%s'", key);
+    return APT_OK;
+range:
+    return apt::set_error(APT_ERR_ARG, "apt_context_set_debug: value out of range for '%s'", key);
+}
+uint32_t *apt_context::status_lookup(int dev) {
+    if (dev < 0 || dev >= apt::kMaxStatusDevices) return nullptr;
+    std::lock_guard<std::mutex> g(m_);
+    return status_[dev];
+}
+uint32_t *apt_context::status_adopt(int dev, uint32_t *fresh, uint32_t **spare) {
+    *spare = nullptr;
+    if (dev < 0 || dev >= apt::kMaxStatusDevices) { *spare = fresh; return nullptr; }
+    std::lock_guard<std::mutex> g(m_);
+    if (status_[dev]) *spare = fresh;
+    else status_[dev] = fresh;
+    return status_[dev];
+}
+void apt_context::status_release(uint32_t *out[apt::kMaxStatusDevices]) {
+    std::lock_guard<std::mutex> g(m_);
+    for (int i = 0; i < apt::kMaxStatusDevices; ++i) { out[i] = status_[i]; status_[i] = nullptr; }
+}
 
 namespace {
 using apt::set_error;
@@ -231,7 +281,7 @@ int apt_gen_scene_host(uint32_t num_spheres, uint64_t seed, float *spheres, size
 // they go to an always-tested list; the others are binned by their bounding boxes, inflated by `margin`
 // so that any ray the fp32 intersection formula can possibly accept passes through the interior of a
 // cell that lists the sphere (the formula's absolute error on disc is ~1e-3 at these coordinates; the
-// margin is 0.05 + 1e-4 * coordinate scale).  Cells are sized for kGridSpheresPerCell = 0.5 sphere centres each (APT_GRID_SPHERES_PER_CELL overrides: tuning knob).
+// margin is 0.05 + 1e-4 * coordinate scale).  Cells are sized for kGridSpheresPerCell = 0.5 sphere centres each (apt_set_debug("grid_spheres_per_cell", v) overrides: tuning knob).
 int apt_build_grid_host(const float *sph, uint32_t ns, void *grid, size_t *out_bytes) {
     apt::clear_error();
     if (!sph || ns == 0 || !out_bytes) return set_error(APT_ERR_ARG, "apt_build_grid_host: spheres/out_bytes must be non-null, num_spheres non-zero%s");
@@ -252,8 +302,8 @@ int apt_build_grid_host(const float *sph, uint32_t ns, void *grid, size_t *out_b
     // sphere centres per cell (boxes overlap ~4 cells each).  The nested walk (round 1, 64 spp): 74.4 / 70.7 / 70.3 / 70.8 / 72.2 ms at 2 / 1 / 0.7 /
     // 0.5 / 0.35; the sample-queue kernel's grid form (round 3): 66.8 / 60.1 / 58.8 / 58.4 / 59.0 / 60.5 / 63.6 ms at 2 / 1 / 0.7 / 0.5 / 0.35 / 0.25 /
     // 0.18 -- a cell step is cheaper there than a pair slot, so smaller cells pay a little longer.
-    double per_cell = apt::kGridSpheresPerCell;
-    if (const char *e = getenv("APT_GRID_SPHERES_PER_CELL")) { const double v = atof(e); if (v > 0.01 && v < 1e6) per_cell = v; }
+    const double knob = apt::default_context().snapshot().debug.grid_spheres_per_cell;   // apt_set_debug("grid_spheres_per_cell", v): tuning knob
+    const double per_cell = knob > 0.0 ? knob : apt::kGridSpheresPerCell;
     apt::GridHeader h;
     apt::grid_header_from_stats(ns, (uint32_t)small.size(), (uint32_t)large.size(), lo, hi, scale, per_cell, h);
     std::vector<uint32_t> count(h.ncells + 1, 0);

@@ -162,9 +162,10 @@ __global__ __launch_bounds__(kBlock) void render_paths_queue_kernel(const float 
 // TWO: two samples of a lane's chain are traced at a time (pt_trace2.h); only with SC == kScene8, GROUP == 8, no
 // retirement, no roulette (the host picks the kernel).
 template <int MODE, int SC, int GROUP, bool RETIRE, bool TWO = false>
-__global__ __launch_bounds__(kBlock, TWO ? APT_TWO_WAVES : (RETIRE && SC == kScene8 && GROUP == 8) ? APT_QUEUE_WAVES : (SC == kSceneGrid ? APT_GRID_WAVES : (SC == kSceneTiles ? APT_TILE_WAVES : APT_FULL_WAVES))) void render_frame_kernel(const float *__restrict__ sph, FrameArgs fa,
+__global__ __launch_bounds__(kBlock, TWO ? APT_TWO_WAVES : (SC == kSceneGrid ? APT_GRID_WAVES : (SC == kSceneTiles ? APT_TILE_WAVES : APT_FULL_WAVES))) void render_frame_kernel(const float *__restrict__ sph, FrameArgs fa,
                                                               TraceArgs ta, LeafProg lp) {
     constexpr bool NS8 = SC == kScene8;
+    static_assert(!(RETIRE && NS8 && GROUP == 8), "APT_FLAG_RETIRE on the 8-sphere scene with samples >= 8 is render_frame_queue8_kernel's (pt_queue.h)");
     if (SC == kSceneGrid && ta.grid_walk == 2u && grid_queue_usable(ta)) return;   // the sample-queue kernel's grid form renders this frame (pt_queue.h)
     __shared__ float4 tab[kTab8Floats4];
     __shared__ float4 tile[SC == kSceneTiles ? kTile : 1];
@@ -181,8 +182,6 @@ __global__ __launch_bounds__(kBlock, TWO ? APT_TWO_WAVES : (RETIRE && SC == kSce
     else __syncthreads();
     const bool planes = NS8 && sc.planes;   // wave-uniform: the reference scene's axis-aligned walls (pt_trace.h)
     (void)planes;
-    const KeyConsts kc = make_key_consts(ta.eps);      // refill queue only (trace_ns8 makes its own)
-    const bool fast_ok = eps_allows_rootkey(ta.eps);
 
     const uint32_t lane = threadIdx.x & 63;
     const uint64_t L = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -243,13 +242,11 @@ __global__ __launch_bounds__(kBlock, TWO ? APT_TWO_WAVES : (RETIRE && SC == kSce
             acc[0] = a.r; acc[1] = a.g; acc[2] = a.b;
         } else {          // 8 <= n <= 128: r[j] chains, tree, tail
             const uint32_t nfull = n & ~7u;
-            if (RETIRE && (NS8 || SC == kSceneTiles)) {
-                // Active-ray compaction with a wave-level work queue (the 8-sphere scene, and any scene by brute force
-                // over LDS tiles, where a "bounce" is one workgroup-synchronous pass over the scene).  (The same queue around grid_segment() for large
-                // scenes is bit-identical but slower than the plain per-lane walk with wave-level early exit -- C4 256 spp:
-                // 288 / 318 / 371 ms at 6 / 5 / 4 waves per SIMD against 232 ms: the walk is latency bound and the queue's
-                // extra state costs occupancy; measured in round 2, not kept.)  The 8 sub-pixel groups of the
-                // wave have 8*nfull samples in this leaf; instead of binding sample k of group g to
+            if (RETIRE && SC == kSceneTiles) {
+                // Active-ray compaction with a wave-level work queue for scenes traversed by brute force over LDS tiles, where a
+                // "bounce" is one workgroup-synchronous pass over the scene.  (The 8-sphere scene and scenes behind a grid have their own
+                // kernel for this, pt_queue.h; round 2's form of this queue for the 8-sphere scene lived here until round 4.)  The 8
+                // sub-pixel groups of the wave have 8*nfull samples in this leaf; instead of binding sample k of group g to
                 // lane (g, k mod 8), any lane that runs out of work takes the next unissued sample:
                 // a ballot of the lanes with an empty one-ray slot, a prefix count (mbcnt) as the
                 // rank inside the batch, item = next + rank.  Finished colours are parked in a
@@ -266,17 +263,8 @@ __global__ __launch_bounds__(kBlock, TWO ? APT_TWO_WAVES : (RETIRE && SC == kSce
                 uint32_t n_bounce_exec = 0, n_gen_exec = 0; // wave-level executions (statistics only)
                 float sl_ox = 0.f, sl_oy = 0.f, sl_oz = 0.f, sl_dx = 0.f, sl_dy = 0.f, sl_dz = 1.f; // the one-ray slot
                 bool slot_full = false, slot_valid = false, cur_valid = false;
-                // The loop is written as refill / bounce / refill / bounce with the two bounces exchanging the roles of
-                // the state registers (no copies), the throughput and the alive mask outside that pair (updated in place),
-                // and WITHOUT a merge of the fast and the exact form of a bounce: when a lane whose path can still reach an
-                // output leaves the validity range of the fast sequences, the wave finishes this leaf in the exact loop
-                // below (same queue logic around bounce_ns8<MODE, false>; about 1e-5 of the wave-bounces).
-                PathState s, n;
+                PathState s;
                 path_init(s, 0.f, 0.f, 0.f, 0.f, 0.f, 1.f);
-                n = s;
-                f2 thr_xy = {1.0f, 1.0f};                 // throughput of the lane's running path
-                float thr_z = 1.0f;
-                uint64_t alive = 0;                       // wave mask: running path has not hit the light
                 // Take unissued samples into the one-ray slots (wave-wide float64 ray-generate when enough lanes want one),
                 // start waiting rays in `cur`; -> true when the wave has nothing left to do in this leaf.
                 auto refill = [&](PathState &cur) -> bool {
@@ -316,8 +304,7 @@ __global__ __launch_bounds__(kBlock, TWO ? APT_TWO_WAVES : (RETIRE && SC == kSce
                         const bool begin = depth_left == 0 && slot_full; // start the waiting ray
                         if (begin) {
                             cur.oxy = f2{sl_ox, sl_oy}; cur.oz = sl_oz; cur.dxy = f2{sl_dx, sl_dy}; cur.dz = sl_dz;
-                            thr_xy = f2{1.0f, 1.0f}; thr_z = 1.0f;
-                            if (!NS8) { cur.rxy = f2{1.0f, 1.0f}; cur.rz = 1.0f; cur.alive = 1u; } // the tile form keeps these in the state
+                            cur.rxy = f2{1.0f, 1.0f}; cur.rz = 1.0f; cur.alive = 1u;
                             cur_item = slot_item;
                             cur_key = slot_key;
                             cur_valid = slot_valid;
@@ -328,92 +315,29 @@ __global__ __launch_bounds__(kBlock, TWO ? APT_TWO_WAVES : (RETIRE && SC == kSce
                                 colq[cur_item] = gain.r; colq[qstride + cur_item] = gain.g; colq[2 * qstride + cur_item] = gain.b;
                             }
                         }
-                        alive |= __builtin_amdgcn_ballot_w64(begin);
                         if (__any(depth_left != 0)) return false;
                         if (next >= total && !__any(slot_full)) return true;
                     }
                 };
-                // bookkeeping after a bounce that stands: roulette, counters, finished paths park their colour
-                auto post = [&](bool active) {
+                // The scene pass contains workgroup barriers, so the four waves of the workgroup take their passes together and
+                // leave together; a wave whose queue is empty keeps staging tiles with all its lanes inactive.  Every lane does
+                // the same work per segment here, so what the queue buys is exactly the dead lane-segments (19 % at depth 8 on
+                // the 10 000-sphere scene, most of them with roulette).
+                for (;;) {
+                    const bool wave_done = refill(s);
+                    if (__syncthreads_and(wave_done)) break;
+                    const bool active = depth_left != 0;
+                    dyn_segment<MODE>(sph, tile, s, !active, ta);
                     ++n_bounce_exec;
-                    if (ta.rr_start && ta.depth - depth_left + 1 >= ta.rr_start) { // 0-based bounce index = depth - depth_left
-                        PathState t;
-                        t.rxy = thr_xy; t.rz = thr_z; t.alive = select_const(alive, 1);
-                        russian_roulette(t, cur_key, ta.depth - depth_left);
-                        thr_xy = t.rxy; thr_z = t.rz;
-                    }
+                    if (active && ta.rr_start && ta.depth - depth_left + 1 >= ta.rr_start)
+                        russian_roulette(s, cur_key, ta.depth - depth_left);
                     queue_traced += (active && cur_valid) ? 1u : 0u; // the item's pixel decides, not this lane's own
                     depth_left -= active ? 1u : 0u;
-                    const bool fin = select_const(alive, 1) == 0 || (thr_xy.x == 0.0f && thr_xy.y == 0.0f && thr_z == 0.0f);
-                    if (active && (depth_left == 0 || fin)) {
+                    if (active && (depth_left == 0 || path_finished(s))) {
                         depth_left = 0;
-                        colq[cur_item] = thr_xy.x * gain.r;
-                        colq[qstride + cur_item] = thr_xy.y * gain.g;
-                        colq[2 * qstride + cur_item] = thr_z * gain.b;
-                    }
-                };
-                // one fast bounce cur -> nxt (inactive lanes compute on stale state; whatever they hold is overwritten when
-                // they start their next ray); true: the wave must go exact from `cur`, nothing was committed
-                auto step_fast = [&](const PathState &cur, PathState &nxt) -> bool {
-                    const bool active = depth_left != 0;
-                    Albedo albedo;
-                    uint64_t alive_out = alive;
-                    const uint64_t redo = bounce_ns8_v2p<MODE>(sc, tab8, cur, nxt, ta, kc, alive_out, albedo, sc.planes) & __builtin_amdgcn_ballot_w64(active);
-                    if (__builtin_expect(redo != 0, 0)) { // a finished path's request is ignored, see trace_ns8
-                        const bool fin = select_const(alive, 1) == 0 || (thr_xy.x == 0.0f && thr_xy.y == 0.0f && thr_z == 0.0f);
-                        if (__any(select_const(redo, 1) != 0 && !fin)) return true;
-                    }
-                    apply_albedo(thr_xy, thr_z, albedo, alive_out);
-                    alive = alive_out;
-                    post(active);
-                    return false;
-                };
-                auto step_exact = [&](PathState &cur, PathState &nxt) {
-                    const bool active = depth_left != 0;
-                    cur.rxy = thr_xy; cur.rz = thr_z; cur.alive = select_const(alive, 1);
-                    (void)bounce_ns8<MODE, false>(sc, tab8, cur, nxt, ta);
-                    thr_xy = nxt.rxy; thr_z = nxt.rz;
-                    alive = __builtin_amdgcn_ballot_w64(nxt.alive != 0);
-                    post(active);
-                };
-                if (!NS8) {
-                    // LDS-tile traversal: the scene pass contains workgroup barriers, so the four waves of the workgroup take
-                    // their passes together and leave together; a wave whose queue is empty keeps staging tiles with all its
-                    // lanes inactive.  Every lane does the same work per segment here, so what the queue buys is exactly the
-                    // dead lane-segments (19 % at depth 8 on the 10 000-sphere scene, most of them with roulette).
-                    for (;;) {
-                        const bool wave_done = refill(s);
-                        if (__syncthreads_and(wave_done)) break;
-                        const bool active = depth_left != 0;
-                        dyn_segment<MODE>(sph, tile, s, !active, ta);
-                        ++n_bounce_exec;
-                        if (active && ta.rr_start && ta.depth - depth_left + 1 >= ta.rr_start)
-                            russian_roulette(s, cur_key, ta.depth - depth_left);
-                        queue_traced += (active && cur_valid) ? 1u : 0u;
-                        depth_left -= active ? 1u : 0u;
-                        if (active && (depth_left == 0 || path_finished(s))) {
-                            depth_left = 0;
-                            colq[cur_item] = s.rxy.x * gain.r;
-                            colq[qstride + cur_item] = s.rxy.y * gain.g;
-                            colq[2 * qstride + cur_item] = s.rz * gain.b;
-                        }
-                    }
-                }
-                bool done = !NS8 || refill(s), exact = !fast_ok;
-                if (!done && !exact) {
-                    for (;;) {
-                        if (__builtin_expect(step_fast(s, n), 0)) { exact = true; break; }
-                        if ((done = refill(n))) break;
-                        if (__builtin_expect(step_fast(n, s), 0)) { exact = true; s = n; break; }
-                        if ((done = refill(s))) break;
-                    }
-                }
-                if (!done && exact) {
-                    if (ta.traced && lane == 0) atomicAdd(ta.traced + 3, 1ull); // statistics: waves that left the fast loop
-                    for (;;) {
-                        step_exact(s, n);
-                        s = n;
-                        if (refill(s)) break;
+                        colq[cur_item] = s.rxy.x * gain.r;
+                        colq[qstride + cur_item] = s.rxy.y * gain.g;
+                        colq[2 * qstride + cur_item] = s.rz * gain.b;
                     }
                 }
                 __syncthreads(); // colours of the whole leaf are in LDS (only wave-local data is read back)

@@ -88,7 +88,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SC == kScene
     const uint32_t lane = threadIdx.x;
     // No static LDS in this kernel, so the dynamic region starts at LDS address 0 (tests/test_isa_hazards.py checks the kernel
     // descriptor's group_segment_fixed_size); a build that breaks this renders nothing rather than reading the wrong pool entries.
-    if ((uint32_t)(uintptr_t)qlds != 0u) return;
+    if ((uint32_t)(uintptr_t)qlds != 0u) { report_status(ta, APT_DEV_LDS_BASE); return; }
     if (SC == kSceneGrid && !grid_queue_usable(ta)) return;            // wave-uniform: render_frame_kernel renders this frame (grid_walk == 2)
     if (lane < sizeof(Camera) / sizeof(double)) (&cam.pos[0])[lane] = (&fa.cam.pos[0])[lane];
     Scene8 sc;
@@ -405,7 +405,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SC == kScene
     // The hot loop: one bounce per turn, in place (no ping-pong pair: the cold exact block of step() merges into the same registers).
     // `guard`: an upper bound of the loop turns a wave can need (every turn either bounces an active lane or issues rays),
     // so that a logic error can never leave a wave spinning on the GPU.
+#ifdef APT_TEST_TINY_GUARD   // test build only (tests/test_gpu_boundary.py): the bound trips at once, the status word must say so
+    uint32_t guard = 3u;
+#else
     uint32_t guard = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)min(4ull * ((uint64_t)npx * 4u * S * ((uint64_t)ta.depth + 1u) + 64u), 0xffffffffull));
+#endif
     auto run = [&](auto planes_tag) __attribute__((always_inline)) {
 #ifndef APT_QUEUE_JOIN_LOOP
         {
@@ -417,7 +421,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SC == kScene
             while (!finished) {
                 bool need_exact = false;
                 for (;;) {
-                    if (service(s) || guard-- == 0u) { finished = true; break; }
+                    if (service(s)) { finished = true; break; }
+                    if (__builtin_expect(guard-- == 0u, 0)) { report_status(ta, APT_DEV_QUEUE_GUARD); finished = true; break; }
                     Bounce8Mid mid;
                     bool redo_any = !fast_ok;
                     if (__builtin_expect(fast_ok, 1)) {
@@ -449,7 +454,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SC == kScene
         }
 #else   // (measurement: fast and exact arm of the bounce joined inside one loop, step() above)
         for (;;) {
-            if (service(s) || guard-- == 0u) break;
+            if (service(s)) break;
+            if (__builtin_expect(guard-- == 0u, 0)) { report_status(ta, APT_DEV_QUEUE_GUARD); break; }
             step(s, planes_tag);
         }
 #endif
@@ -720,7 +726,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SC == kScene
         const uint32_t batch_lanes = ta.refill_lanes;          // waiting lanes that trigger the per-segment block (apt_set_refill_lanes; default 32)
         // upper bound of the loop turns (a turn advances a walking lane by a cell or a slot, or a transition issues / shades):
         // protection against a logic error, never reached
+#ifdef APT_TEST_TINY_GUARD
+        uint64_t turns_left = 3u;
+#else
         uint64_t turns_left = ((uint64_t)npx * 4u * S * ((uint64_t)ta.depth + 1u) + 64u) * ((uint64_t)h.n[0] + h.n[1] + h.n[2] + 5u + h.nslots);
+#endif
         for (;;) {
             const uint64_t waiting = ~walking;                  // finished segments, fresh lanes and lanes without a path
             const uint32_t nwait = (uint32_t)__popcll(waiting & active) + ((pool_level != 0 || g_unit < U) ? (uint32_t)__popcll(~active) : 0u);
@@ -728,7 +738,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SC == kScene
                 transition(waiting);
                 if (active == 0) break;                         // nothing runs, nothing could be issued: everything is parked
             }
-            if (turns_left-- == 0u) break;
+            if (__builtin_expect(turns_left-- == 0u, 0)) { report_status(ta, APT_DEV_GRID_TURNS); break; }
             turn();
         }
         if (ta.traced) {                                        // statistics: cells visited / candidates tested (grid_stats)
@@ -741,7 +751,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SC == kScene
     if (SC == kSceneGrid) run_grid();
     else if (sc.planes) run(std::true_type{});
     else run(std::false_type{});
-    // No lane is active, the pool is empty and every unit has been generated: every item is parked.
+    // No lane is active, the pool is empty and every unit has been generated: every item is parked.  (After a tripped loop bound the
+    // sums below read items that were never parked: the frame is incomplete and the status word says so.)
     while (a_unit < U) accumulate_unit();
 
     if (ta.traced && lane == 0) {

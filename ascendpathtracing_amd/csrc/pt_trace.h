@@ -9,6 +9,7 @@
 #include <stdint.h>
 
 #include "pt_core.h"
+#include "pt_leaf.h"
 
 namespace {
 
@@ -18,7 +19,6 @@ using namespace apt;
 constexpr int kBlock = 256;      // 4 waves
 constexpr int kScene8 = 0, kSceneTiles = 1, kSceneGrid = 2; // template parameter SC: how the scene reaches the lanes
 constexpr int kTile = 1024;      // spheres per LDS tile (16 KB)
-constexpr int kMaxLeaves = 64;   // pairwise-sum leaves -> samples <= 8192
 #ifndef APT_GRID_WAVES
 #define APT_GRID_WAVES 8 // min waves per SIMD requested for the grid-walk kernels: the walk is latency bound
                          // (dependent cell -> item loads), measured 464 / 371 / 334 / 311 / 302 ms at 3 / 4 / 5 / 6 / 8 waves
@@ -28,9 +28,6 @@ constexpr int kMaxLeaves = 64;   // pairwise-sum leaves -> samples <= 8192
 #endif
 #ifndef APT_TWO_WAVES
 #define APT_TWO_WAVES 4 // min waves per SIMD of the two-paths-per-lane frame kernel (pt_trace2.h): twice the path state
-#endif
-#ifndef APT_QUEUE_WAVES
-#define APT_QUEUE_WAVES 6 // min waves per SIMD of the 8-sphere frame kernel with the wave-level sample queue (APT_FLAG_RETIRE)
 #endif
 #ifndef APT_FULL_WAVES
 #define APT_FULL_WAVES 6 // min waves per SIMD requested for the full-trace frame kernel: caps it at 80 VGPRs (the scheduler
@@ -75,15 +72,13 @@ struct TraceArgs {
     uint32_t grid_walk;         // frame kernels: 0 = render_frame_kernel walks the grid (nested item walk); 2 = it returns at once when
                                 // the sample-queue kernel's grid form renders this frame (grid_queue_usable)
     unsigned long long *traced; // optional device counter of traced segments
+    uint32_t *status;           // the context's device status word (include/render_mi355x.h APT_DEV_*), or null
 };
-
-struct LeafProg { // numpy pairwise_sum recursion flattened (see build_leaves)
-    uint32_t nleaves;
-    uint32_t maxleaf;          // longest leaf (sizes the refill colour queue)
-    uint32_t leaf[kMaxLeaves]; // len | ncomb << 16 (dwords: wave-uniform s_load from the kernarg segment)
-    __host__ __device__ uint32_t len(uint32_t i) const { return leaf[i] & 0xffffu; }
-    __host__ __device__ uint32_t ncomb(uint32_t i) const { return leaf[i] >> 16; }
-};
+// A kernel that has to give up says so (the reference asserts inside its kernel: src/render.cpp:68-73): one lane ORs the bit into the
+// context's status word; apt_context_check() reports it as APT_ERR_DEVICE.
+__device__ __forceinline__ void report_status(const TraceArgs &ta, uint32_t bit) {
+    if (ta.status && (threadIdx.x & 63u) == 0u) atomicOr(ta.status, bit);
+}
 
 // Discriminants of TWO spheres per instruction: the tile is stored as sphere pairs,
 //   tile[2p]   = (cx[2p], cx[2p+1], cy[2p], cy[2p+1])      tile[2p+1] = (cz[2p], cz[2p+1], r2[2p], r2[2p+1])

@@ -31,26 +31,8 @@ using apt::clear_error;
 int fail(int code, const char *fmt, const char *detail = "") { return apt::set_error(code, fmt, detail); }
 int hip_fail(hipError_t e) { return fail(APT_ERR_DEVICE, "HIP: %s", hipGetErrorString(e)); }
 
-void build_leaves(uint32_t n, std::vector<std::pair<uint32_t, uint32_t>> &out) {
-    if (n <= 128) { out.push_back({n, 0u}); return; }
-    uint32_t n2 = n / 2;
-    n2 -= n2 % 8;
-    build_leaves(n2, out);
-    build_leaves(n - n2, out);
-    out.back().second += 1;
-}
-
-int make_leaf_prog(uint32_t samples, LeafProg &lp) {
-    std::vector<std::pair<uint32_t, uint32_t>> v;
-    build_leaves(samples, v);
-    if (v.size() > (size_t)kMaxLeaves) return fail(APT_ERR_ARG, "samples too large for the pairwise plan (max 8192)%s");
-    memset(&lp, 0, sizeof lp);
-    lp.nleaves = (uint32_t)v.size();
-    for (size_t i = 0; i < v.size(); ++i) {
-        lp.leaf[i] = v[i].first | (v[i].second << 16);
-        lp.maxleaf = v[i].first > lp.maxleaf ? v[i].first : lp.maxleaf;
-    }
-    return APT_OK;
+int make_leaf_prog(uint32_t samples, LeafProg &lp) {   // the plan itself: pt_leaf.h
+    return make_leaf_plan(samples, lp) ? APT_OK : fail(APT_ERR_ARG, "samples too large: its pairwise-sum plan needs more than 64 leaves (every count <= 7688 fits, and 8192)%s");
 }
 
 int check_params(const apt_render_params *p) {
@@ -64,10 +46,37 @@ int check_params(const apt_render_params *p) {
     return APT_OK;
 }
 
-TraceArgs make_trace_args(const apt_render_params *p, const apt_context::Values &cv) {
+// The device status word of `ctx` on the current device (include/render_mi355x.h "Device-side failure channel"), made on the
+// context's first launch there: 4 bytes of device memory, once.  Null -- the kernels then report nothing -- when it does not exist yet
+// and cannot be made now (the stream is being captured, or the allocation failed).
+uint32_t *status_word(apt_context &ctx, hipStream_t st) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    if (uint32_t *w = ctx.status_lookup(dev)) return w;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    if (cs != hipStreamCaptureStatusNone) return nullptr;
+    uint32_t *fresh = nullptr, *spare = nullptr;
+    if (hipMalloc(&fresh, sizeof(uint32_t)) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    if (hipMemset(fresh, 0, sizeof(uint32_t)) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(fresh); return nullptr; }
+    uint32_t *w = ctx.status_adopt(dev, fresh, &spare);
+    if (spare) (void)hipFree(spare);      // another thread was first (or the device index is beyond the table)
+    return w;
+}
+
+// What a render call needs from its context: one consistent copy of the values and the status word of the current device.
+struct Launch {
+    apt_context::Values cv;
+    uint32_t *status;
+};
+Launch launch_state(apt_context &ctx, void *stream) { return Launch{ctx.snapshot(), status_word(ctx, (hipStream_t)stream)}; }
+
+TraceArgs make_trace_args(const apt_render_params *p, const Launch &ls) {
+    const apt_context::Values &cv = ls.cv;
     TraceArgs ta;
     ta.ns = p->num_spheres; ta.depth = p->depth; ta.light = p->light_index;
     ta.eps = p->eps; ta.gain = p->gain; ta.traced = cv.trace_counter;
+    ta.status = ls.status;
     ta.refill_lanes = cv.refill_lanes;
     ta.grid = (p->num_spheres != 8) ? reinterpret_cast<const uint32_t *>((uintptr_t)p->accel) : nullptr;
     ta.grid_walk = 0;
@@ -87,8 +96,14 @@ void launch_paths(bool retire, dim3 grid, hipStream_t st, const float *rays, con
 template <int MODE, int SC, int GROUP>
 void launch_frame(bool retire, dim3 grid, size_t lds, hipStream_t st, const float *sph, const FrameArgs &fa,
                   const TraceArgs &ta, const LeafProg &lp) {
-    if (retire) hipLaunchKernelGGL((render_frame_kernel<MODE, SC, GROUP, true>), grid, dim3(kBlock), lds, st, sph, fa, ta, lp);
-    else hipLaunchKernelGGL((render_frame_kernel<MODE, SC, GROUP, false>), grid, dim3(kBlock), lds, st, sph, fa, ta, lp);
+    if constexpr (SC == kScene8 && GROUP == 8) {
+        // With APT_FLAG_RETIRE these frames belong to the sample-queue kernel (pt_queue.h); what arrives here with the flag set is
+        // depth 0, where there is nothing to retire.  (Round 2's wave queue inside render_frame_kernel for this case is gone.)
+        hipLaunchKernelGGL((render_frame_kernel<MODE, SC, GROUP, false>), grid, dim3(kBlock), lds, st, sph, fa, ta, lp);
+    } else {
+        if (retire) hipLaunchKernelGGL((render_frame_kernel<MODE, SC, GROUP, true>), grid, dim3(kBlock), lds, st, sph, fa, ta, lp);
+        else hipLaunchKernelGGL((render_frame_kernel<MODE, SC, GROUP, false>), grid, dim3(kBlock), lds, st, sph, fa, ta, lp);
+    }
 }
 
 template <int MODE, int SC>
@@ -104,7 +119,7 @@ void launch_frame_g(int group, bool retire, dim3 grid, size_t lds, hipStream_t s
 }
 
 // ---- the two render launches, on an explicit snapshot of a context's values -----------------
-int do_render_paths(const apt_context::Values &cv, const apt_render_params *p, void *stream, const float *rays,
+int do_render_paths(const Launch &ls, const apt_render_params *p, void *stream, const float *rays,
                     const float *spheres, float *colors) {
     int rc = check_params(p);
     if (rc) return rc;
@@ -119,7 +134,7 @@ int do_render_paths(const apt_context::Values &cv, const apt_render_params *p, v
     if (blocks > 0x7fffffffull) return fail(APT_ERR_ARG, "path_count too large for one launch; shard it%s");
     hipStream_t st = (hipStream_t)stream;
     const bool ns8 = p->num_spheres == 8;
-    const TraceArgs ta = make_trace_args(p, cv);
+    const TraceArgs ta = make_trace_args(p, ls);
     const bool retire = p->flags & APT_FLAG_RETIRE;
     const dim3 grid((unsigned)blocks);
     const int sck = ns8 ? kScene8 : (ta.grid ? kSceneGrid : kSceneTiles);
@@ -147,8 +162,25 @@ int do_render_paths(const apt_context::Values &cv, const apt_render_params *p, v
     return e == hipSuccess ? APT_OK : hip_fail(e);
 }
 
-int do_render_frame(const apt_context::Values &cv, const apt_render_params *p, void *stream, const float *spheres,
+// The sample-queue kernels' launch shape (pt_queue.h): colour buffers, pixels per wave, dynamic LDS.  -> false: too many waves.
+bool queue_launch_shape(const apt::Debug &dbg, const LeafProg &lp, bool rr, uint64_t pixel_count, bool retire, QueueArgs &qa, uint64_t &waves,
+                        size_t &qlds) {
+    const uint32_t unit_items = 4u * lp.maxleaf;
+    qa.nbuf = dbg.queue_nbuf ? dbg.queue_nbuf : std::max(2u, std::min(16u, (512u + unit_items - 1u) / unit_items));
+    qa.buf_bytes = queue_buf_bytes(lp.maxleaf);
+    qa.retire = retire ? 1u : 0u;
+    // pixels per wave: 16 at C2 (lane efficiency 0.98; 8 / 16 / 24 measured within 0.5 % of each other, 2 costs 6 %), fewer only
+    // for frames too small to fill the chip's ~3800 wave slots a few times over
+    const uint64_t ppw = dbg.queue_ppw ? dbg.queue_ppw : std::max<uint64_t>(4, std::min<uint64_t>(16, pixel_count / 8192u));
+    qa.ppw = (uint32_t)ppw;
+    waves = (pixel_count + ppw - 1) / ppw;
+    qlds = queue_lds_bytes(rr, qa.nbuf, lp.nleaves > 1, qa.buf_bytes) + dbg.queue_lds_pad;   // the pad: experiments only, lowers the occupancy
+    return waves <= 0x7fffffffull;
+}
+
+int do_render_frame(const Launch &ls, const apt_render_params *p, void *stream, const float *spheres,
                     uint64_t pixel_begin, uint64_t pixel_count, float *fb, uint8_t *fb_u8) {
+    const apt::Debug &dbg = ls.cv.debug;
     int rc = check_params(p);
     if (rc) return rc;
     if (!spheres || !fb) return fail(APT_ERR_ARG, "spheres/fb must be non-null%s");
@@ -163,30 +195,19 @@ int do_render_frame(const apt_context::Values &cv, const apt_render_params *p, v
     if (blocks > 0x7fffffffull) return fail(APT_ERR_ARG, "pixel_count too large for one launch; shard it%s");
     hipStream_t st = (hipStream_t)stream;
     const bool ns8 = p->num_spheres == 8;
-    const TraceArgs ta = make_trace_args(p, cv);
+    const TraceArgs ta = make_trace_args(p, ls);
     FrameArgs fa;
     camera_init(fa.cam, p->width, p->height);
     fa.width = p->width; fa.height = p->height; fa.samples = p->samples; fa.seed = p->seed;
     fa.pixel_begin = pixel_begin; fa.pixel_count = pixel_count; fa.fb = fb; fa.fb_u8 = fb_u8;
     const bool retire = p->flags & APT_FLAG_RETIRE;
-    if (retire && ns8 && group == 8 && p->depth > 0 && !getenv("APT_OLD_QUEUE")) {
+    if (retire && ns8 && group == 8 && p->depth > 0) {
         // 8-sphere scene with compaction: one wave per workgroup, a stream of `ppw` pixels per wave (pt_queue.h)
         QueueArgs qa;
-        const uint32_t unit_items = 4u * lp.maxleaf;
-        qa.nbuf = std::max(2u, std::min(16u, (512u + unit_items - 1u) / unit_items));
-        qa.buf_bytes = queue_buf_bytes(lp.maxleaf);
-        qa.retire = 1u;
-        // pixels per wave: 16 at C2 (lane efficiency 0.98; 8 / 16 / 24 measured within 0.5 % of each other, 2 costs 6 %), fewer only
-        // for frames too small to fill the chip's ~3800 wave slots a few times over
-        uint64_t ppw = std::max<uint64_t>(4, std::min<uint64_t>(16, pixel_count / 8192u));
-        if (const char *env = getenv("APT_QUEUE_PPW")) { const long v = atol(env); if (v >= 1 && v <= 4096) ppw = (uint64_t)v; }
-        qa.ppw = (uint32_t)ppw;
-        const uint64_t waves = (pixel_count + ppw - 1) / ppw;
-        if (waves > 0x7fffffffull) return fail(APT_ERR_ARG, "pixel_count too large for one launch; shard it%s");
-        if (const char *env = getenv("APT_QUEUE_NBUF")) { const long v = atol(env); if (v >= 2 && v <= 16) qa.nbuf = (uint32_t)v; }   // experiments only
-        size_t qlds = queue_lds_bytes(ta.rr_start != 0, qa.nbuf, lp.nleaves > 1, qa.buf_bytes);
-        if (const char *env = getenv("APT_QUEUE_LDS_PAD")) { const long v = atol(env); if (v > 0 && v <= 32768) qlds += (size_t)v; }  // experiments only: lowers the occupancy
+        uint64_t waves;
+        size_t qlds;
         const bool rrk = ta.rr_start != 0;
+        if (!queue_launch_shape(dbg, lp, rrk, pixel_count, true, qa, waves, qlds)) return fail(APT_ERR_ARG, "pixel_count too large for one launch; shard it%s");
         if (p->mode == APT_MODE_ORACLE) {
             if (rrk) hipLaunchKernelGGL((render_frame_queue8_kernel<kModeOracle, true>), dim3((unsigned)waves), dim3(64), qlds, st, spheres, fa, ta, lp, qa);
             else hipLaunchKernelGGL((render_frame_queue8_kernel<kModeOracle, false>), dim3((unsigned)waves), dim3(64), qlds, st, spheres, fa, ta, lp, qa);
@@ -198,23 +219,16 @@ int do_render_frame(const apt_context::Values &cv, const apt_render_params *p, v
         return e == hipSuccess ? APT_OK : hip_fail(e);
     }
     TraceArgs ta_frame = ta;
-    if (!ns8 && ta.grid && group == 8 && p->depth > 0 && !(getenv("APT_GRID_WALK") && getenv("APT_GRID_WALK")[0] == 'i')) {
+    if (!ns8 && ta.grid && group == 8 && p->depth > 0 && dbg.grid_walk != 1u) {
         // A scene behind a grid: the sample-queue kernel's grid form (pt_queue.h run_grid), with or without APT_FLAG_RETIRE.  Whether
         // the grid carries the pair-slot tables that form needs is written in the buffer on the DEVICE: rather than reading it back in
         // the launch path, both kernels are launched and each asks grid_queue_usable() -- the one not chosen returns at once.
-        // (APT_GRID_WALK=items: measurement knob, the nested item walk of render_frame_kernel only.)
+        // (apt_set_debug("grid_walk", 1): measurement knob, the nested item walk of render_frame_kernel only.)
         QueueArgs qa;
-        const uint32_t unit_items = 4u * lp.maxleaf;
-        qa.nbuf = std::max(2u, std::min(16u, (512u + unit_items - 1u) / unit_items));
-        qa.buf_bytes = queue_buf_bytes(lp.maxleaf);
-        qa.retire = retire ? 1u : 0u;
-        uint64_t ppw = std::max<uint64_t>(4, std::min<uint64_t>(16, pixel_count / 8192u));
-        if (const char *env = getenv("APT_QUEUE_PPW")) { const long v = atol(env); if (v >= 1 && v <= 4096) ppw = (uint64_t)v; }
-        qa.ppw = (uint32_t)ppw;
-        const uint64_t waves = (pixel_count + ppw - 1) / ppw;
-        if (waves > 0x7fffffffull) return fail(APT_ERR_ARG, "pixel_count too large for one launch; shard it%s");
-        const size_t qlds = queue_lds_bytes(ta.rr_start != 0, qa.nbuf, lp.nleaves > 1, qa.buf_bytes);
+        uint64_t waves;
+        size_t qlds;
         const bool rrk = ta.rr_start != 0;
+        if (!queue_launch_shape(dbg, lp, rrk, pixel_count, retire, qa, waves, qlds)) return fail(APT_ERR_ARG, "pixel_count too large for one launch; shard it%s");
         if (p->mode == APT_MODE_ORACLE) {
             if (rrk) hipLaunchKernelGGL((render_frame_queue8_kernel<kModeOracle, true, kSceneGrid>), dim3((unsigned)waves), dim3(64), qlds, st, spheres, fa, ta, lp, qa);
             else hipLaunchKernelGGL((render_frame_queue8_kernel<kModeOracle, false, kSceneGrid>), dim3((unsigned)waves), dim3(64), qlds, st, spheres, fa, ta, lp, qa);
@@ -227,7 +241,7 @@ int do_render_frame(const apt_context::Values &cv, const apt_render_params *p, v
         ta_frame.grid_walk = 2;
     }
     size_t lds = lp.nleaves > 1 ? (size_t)kMaxStack * 3 * kStackSlots * sizeof(float) : 0;
-    if (retire && (ns8 || !ta.grid) && group == 8) lds += (size_t)(kBlock / 64) * 3 * 8 * lp.maxleaf * sizeof(float); // colour queue
+    if (retire && !ns8 && !ta.grid && group == 8) lds += (size_t)(kBlock / 64) * 3 * 8 * lp.maxleaf * sizeof(float); // colour queue of the LDS-tile form
     const dim3 grid((unsigned)blocks);
     const int sck = ns8 ? kScene8 : (ta.grid ? kSceneGrid : kSceneTiles);
     if (p->mode == APT_MODE_ORACLE) {
@@ -286,7 +300,47 @@ int apt_device_count(void) {
 
 // ---- contexts ---------------------------------------------------------------------------------------
 apt_context *apt_context_create(void) { clear_error(); return new (std::nothrow) apt_context(); }
-void apt_context_destroy(apt_context *ctx) { clear_error(); delete ctx; }
+void apt_context_destroy(apt_context *ctx) {
+    clear_error();
+    if (!ctx) return;
+    uint32_t *words[apt::kMaxStatusDevices];
+    ctx->status_release(words);
+    int cur = 0;
+    const bool have_cur = hipGetDevice(&cur) == hipSuccess;
+    for (int d = 0; d < apt::kMaxStatusDevices; ++d)
+        if (words[d] && hipSetDevice(d) == hipSuccess) (void)hipFree(words[d]);
+    if (have_cur) (void)hipSetDevice(cur);
+    (void)hipGetLastError();
+    delete ctx;
+}
+
+int apt_context_set_debug(apt_context *ctx, const char *key, double value) {
+    clear_error();
+    if (!ctx) return fail(APT_ERR_ARG, "context is null%s");
+    return ctx->set_debug(key, value);
+}
+
+// Reads and clears the status word of the current device (see the header).  Synchronises `stream` first.
+int apt_context_check(apt_context *ctx, void *stream) {
+    clear_error();
+    if (!ctx) return fail(APT_ERR_ARG, "context is null%s");
+    hipError_t e = hipStreamSynchronize((hipStream_t)stream);
+    if (e != hipSuccess) return hip_fail(e);
+    uint32_t *w = status_word(*ctx, (hipStream_t)stream);
+    if (!w) return APT_OK;                       // no word could be made: nothing was ever reported into it
+    uint32_t bits = 0;
+    e = hipMemcpy(&bits, w, sizeof bits, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return hip_fail(e);
+    if (!bits) return APT_OK;
+    e = hipMemset(w, 0, sizeof bits);
+    if (e != hipSuccess) (void)hipGetLastError();
+    std::string what;
+    if (bits & APT_DEV_QUEUE_GUARD) what += " queue-loop-bound";
+    if (bits & APT_DEV_GRID_TURNS) what += " grid-walk-bound";
+    if (bits & APT_DEV_LDS_BASE) what += " lds-base";
+    if (bits & ~(uint32_t)(APT_DEV_QUEUE_GUARD | APT_DEV_GRID_TURNS | APT_DEV_LDS_BASE)) what += " unknown-bits";
+    return fail(APT_ERR_DEVICE, "a kernel reported a failure through the device status word:%s (the frame it wrote is incomplete)", what.c_str());
+}
 
 int apt_context_set_params(apt_context *ctx, const apt_render_params *p) {
     clear_error();
@@ -318,28 +372,30 @@ void apt_context_render_do(apt_context *ctx, uint32_t blockDim, void *l2ctrl, vo
     (void)blockDim; // the reference's 8-way partition (render.cpp:9-10,24): results do not depend on it
     (void)l2ctrl;
     if (!ctx) { (void)fail(APT_ERR_ARG, "context is null%s"); return; }
-    const apt_context::Values cv = ctx->snapshot();
-    (void)do_render_paths(cv, &cv.params, stream, (const float *)rays, (const float *)spheres, (float *)colors);
+    const Launch ls = launch_state(*ctx, stream);
+    (void)do_render_paths(ls, &ls.cv.params, stream, (const float *)rays, (const float *)spheres, (float *)colors);
 }
 
 int apt_context_render_do_ex(apt_context *ctx, const apt_render_params *p, void *stream, const float *rays,
                              const float *spheres, float *colors) {
     clear_error();
     if (!ctx) return fail(APT_ERR_ARG, "context is null%s");
-    return do_render_paths(ctx->snapshot(), p, stream, rays, spheres, colors);
+    return do_render_paths(launch_state(*ctx, stream), p, stream, rays, spheres, colors);
 }
 
 int apt_context_render_frame(apt_context *ctx, const apt_render_params *p, void *stream, const float *spheres,
                              uint64_t pixel_begin, uint64_t pixel_count, float *fb, uint8_t *fb_u8) {
     clear_error();
     if (!ctx) return fail(APT_ERR_ARG, "context is null%s");
-    return do_render_frame(ctx->snapshot(), p, stream, spheres, pixel_begin, pixel_count, fb, fb_u8);
+    return do_render_frame(launch_state(*ctx, stream), p, stream, spheres, pixel_begin, pixel_count, fb, fb_u8);
 }
 
 // ---- the context-free forms: the process-wide default context -----------------------------------------
 int apt_set_default_params(const apt_render_params *p) { return apt_context_set_params(&apt::default_context(), p); }
 int apt_set_refill_lanes(uint32_t lanes) { return apt_context_set_refill_lanes(&apt::default_context(), lanes); }
 int apt_set_trace_counter(uint64_t *device_counter) { return apt_context_set_trace_counter(&apt::default_context(), device_counter); }
+int apt_set_debug(const char *key, double value) { return apt_context_set_debug(&apt::default_context(), key, value); }
+int apt_check(void *stream) { return apt_context_check(&apt::default_context(), stream); }
 
 int render_do_ex(const apt_render_params *p, void *stream, const float *rays, const float *spheres, float *colors) {
     return apt_context_render_do_ex(&apt::default_context(), p, stream, rays, spheres, colors);
@@ -365,12 +421,12 @@ int render_frame(const apt_render_params *p, void *stream, const float *spheres,
 int apt_render_host(uint32_t blockDim, const uint8_t *rays, const uint8_t *spheres, uint8_t *colors) {
     clear_error();
     if (!rays || !spheres || !colors) return fail(APT_ERR_ARG, "rays/spheres/colors must be non-null%s");
-    const apt_context::Values cv = apt::default_context().snapshot();
-    const apt_render_params &p = cv.params;
-    // The reference's call renders the whole ray array (src/main.cpp:18-25); with a path sub-range in the default parameters the
-    // colours outside it would be copied back from memory no kernel wrote.
-    if (p.path_begin != 0 || p.path_count != 0) return fail(APT_ERR_ARG, "apt_render_host: the default parameters carry a path sub-range; it renders whole frames only%s");
+    const Launch ls = launch_state(apt::default_context(), nullptr);
+    const apt_render_params &p = ls.cv.params;
     const size_t n = (size_t)p.width * p.height * 4u * p.samples;
+    // The reference's call renders the whole ray array (src/main.cpp:18-25); with a STRICT path sub-range in the default parameters the
+    // colours outside it would be copied back from memory no kernel wrote.  (path_begin 0 with path_count 0 or N is the whole frame.)
+    if (p.path_begin != 0 || (p.path_count != 0 && p.path_count != n)) return fail(APT_ERR_ARG, "apt_render_host: the default parameters carry a path sub-range; it renders whole frames only%s");
     const size_t sph_bytes = ((size_t)p.num_spheres * 10 + 127) / 128 * 128 * sizeof(float);
     float *d_rays = nullptr, *d_sph = nullptr, *d_col = nullptr;
     hipError_t e = hipMalloc(&d_rays, n * 24);
@@ -381,12 +437,13 @@ int apt_render_host(uint32_t blockDim, const uint8_t *rays, const uint8_t *spher
     int rc = APT_OK;
     if (e == hipSuccess) {
         (void)blockDim;
-        rc = do_render_paths(cv, &p, nullptr, d_rays, d_sph, d_col);
+        rc = do_render_paths(ls, &p, nullptr, d_rays, d_sph, d_col);
         if (rc == APT_OK) e = hipMemcpy(colors, d_col, n * 12, hipMemcpyDeviceToHost); // synchronises the null stream
     }
     (void)hipFree(d_rays); (void)hipFree(d_sph); (void)hipFree(d_col);
     if (rc != APT_OK) return rc;
-    return e == hipSuccess ? APT_OK : hip_fail(e);
+    if (e != hipSuccess) return hip_fail(e);
+    return apt_context_check(&apt::default_context(), nullptr);   // a kernel may have reported a failure (clears and sets the error record itself)
 }
 
 // ---- one process, several GPUs ---------------------------------------------------------------------------
@@ -451,7 +508,6 @@ int apt_multi_create(const int *device_ids, uint32_t num_bands, uint32_t stripes
 int apt_multi_render(apt_multi *m, float *fb_root, uint8_t *u8_root, float *band_kernel_ms) {
     clear_error();
     if (!m || !fb_root) return fail(APT_ERR_ARG, "apt_multi_render: handle/fb must be non-null%s");
-    const apt_context::Values cv = apt::default_context().snapshot();
     const uint64_t npix = (uint64_t)m->params.width * m->params.height;
     const uint64_t nb = m->bands.size(), parts = nb * m->stripes;
     int rc = APT_OK;
@@ -459,16 +515,17 @@ int apt_multi_render(apt_multi *m, float *fb_root, uint8_t *u8_root, float *band
     for (uint64_t b = 0; b < nb && rc == APT_OK && e == hipSuccess; ++b) {
         apt_multi::Band &bd = m->bands[b];
         e = hipSetDevice(bd.device);
-        if (e == hipSuccess) e = hipEventRecord(bd.start, bd.stream);
+        if (e != hipSuccess) break;
+        Launch ls = launch_state(apt::default_context(), bd.stream);   // (the status word is per device: taken with the band's device current)
+        // the statistics block of the default context is an address on ITS device: only bands on the root device may count into it
+        if (bd.device != m->root) ls.cv.trace_counter = nullptr;
+        e = hipEventRecord(bd.start, bd.stream);
         for (uint32_t s = 0; s < m->stripes && rc == APT_OK && e == hipSuccess; ++s) {
             uint64_t begin, count;
             split_range(npix, (uint64_t)s * nb + b, parts, begin, count);   // interleaved: stripe s*nb + b belongs to band b
             float *fb = bd.fb + (size_t)s * 3 * m->max_stripe;
             uint8_t *u8 = bd.u8 + (size_t)s * 3 * m->max_stripe;
-            // the statistics block of the default context is an address on ITS device: only bands on the root device may count into it
-            apt_context::Values cvb = cv;
-            if (bd.device != m->root) cvb.trace_counter = nullptr;
-            rc = do_render_frame(cvb, &m->params, bd.stream, bd.sph, begin, count, fb, u8_root ? u8 : nullptr);
+            rc = do_render_frame(ls, &m->params, bd.stream, bd.sph, begin, count, fb, u8_root ? u8 : nullptr);
             if (rc != APT_OK) break;
             if (s + 1 == m->stripes) e = hipEventRecord(bd.stop, bd.stream);  // kernels only: the copies follow
         }
@@ -492,9 +549,18 @@ int apt_multi_render(apt_multi *m, float *fb_root, uint8_t *u8_root, float *band
             (void)hipSetDevice(m->bands[b].device);
             if (hipEventElapsedTime(&band_kernel_ms[b], m->bands[b].start, m->bands[b].stop) != hipSuccess) band_kernel_ms[b] = -1.0f;
         }
+    int dev_rc = APT_OK;
+    std::string dev_msg;
+    if (rc == APT_OK && e == hipSuccess)   // the device status words of every device that rendered (each check clears its word)
+        for (auto &bd : m->bands)
+            if (hipSetDevice(bd.device) == hipSuccess && apt_context_check(&apt::default_context(), bd.stream) != APT_OK && dev_rc == APT_OK) {
+                dev_rc = apt_last_status();
+                dev_msg = apt_last_error();
+            }
     (void)hipSetDevice(m->root);
-    if (rc != APT_OK) return rc;
-    return e == hipSuccess ? APT_OK : hip_fail(e);
+    if (rc != APT_OK) return rc;             // (the error record still describes the launch that failed: no check ran after it)
+    if (e != hipSuccess) return hip_fail(e);
+    return dev_rc == APT_OK ? APT_OK : fail(dev_rc, "apt_multi_render: %s", dev_msg.c_str());
 }
 
 int apt_build_grid_device(const float *spheres_dev, uint32_t ns, void *stream, void *grid_dev, size_t capacity,
@@ -522,8 +588,8 @@ int apt_build_grid_device(const float *spheres_dev, uint32_t ns, void *stream, v
         if (e == hipSuccess) e = hipStreamSynchronize(st);
     }
     if (e == hipSuccess) {
-        double per_cell = kGridSpheresPerCell;
-        if (const char *env = getenv("APT_GRID_SPHERES_PER_CELL")) { const double v = atof(env); if (v > 0.01 && v < 1e6) per_cell = v; }
+        const double knob = apt::default_context().snapshot().debug.grid_spheres_per_cell;   // apt_set_debug("grid_spheres_per_cell", v)
+        const double per_cell = knob > 0.0 ? knob : kGridSpheresPerCell;
         grid_header_from_stats(ns, stt.nsmall, stt.nlarge, stt.lo, stt.hi, stt.scale, per_cell, h);
         const uint64_t nc1 = (uint64_t)h.ncells + 1, nblk = (nc1 + kGB - 1) / kGB;
         e = hipMalloc(&count, nc1 * 4);
@@ -701,8 +767,7 @@ int apt_render_frame_mt(const apt_render_params *p, void *stream, const uint32_t
     const uint64_t g_lo = pixel_begin / kMtGroupPixels, g_hi = (pixel_begin + pixel_count + kMtGroupPixels - 1) / kMtGroupPixels;
     if (g_lo < first_group || g_hi - first_group > num_checkpoints) return fail(APT_ERR_ARG, "apt_render_frame_mt: the checkpoint table does not cover the pixel range%s");
     if (g_hi - g_lo > 0x7fffffffull) return fail(APT_ERR_ARG, "pixel_count too large for one launch; shard it%s");
-    const apt_context::Values cv = apt::default_context().snapshot();
-    const TraceArgs ta = make_trace_args(p, cv);
+    const TraceArgs ta = make_trace_args(p, launch_state(apt::default_context(), stream));
     FrameArgs fa;
     camera_init(fa.cam, p->width, p->height);
     fa.width = p->width; fa.height = p->height; fa.samples = p->samples; fa.seed = p->seed;

@@ -67,6 +67,14 @@ class Context:
         ptr = ctypes.c_void_p(tensor_or_none.data_ptr()) if tensor_or_none is not None else None
         check(lib().apt_context_set_trace_counter(self._h, ptr), "apt_context_set_trace_counter")
 
+    def set_debug(self, key, value):
+        check(lib().apt_context_set_debug(self._h, key.encode(), ctypes.c_double(value)), "apt_context_set_debug")
+
+    def check(self, stream=None):
+        """apt_context_check: waits for `stream`, raises AptError when a kernel of this context reported a failure through the
+        device status word (the reference asserts inside its kernel, src/render.cpp:68-73)."""
+        check(lib().apt_context_check(self._h, _stream_handle(stream)), "apt_context_check")
+
     def render_do(self, blockDim, l2ctrl, stream, rays, spheres, colors):
         require_gpu()
         lib().apt_context_render_do(self._h, ctypes.c_uint32(blockDim), None, _stream_handle(stream), _dev_f32(rays, "rays"),
@@ -150,6 +158,34 @@ class MultiGpu:
 
 def set_default_params(params):
     check(lib().apt_set_default_params(ctypes.byref(params)), "apt_set_default_params")
+
+
+def set_debug(key, value):
+    """Measurement knob of the default context (include/render_mi355x.h apt_context_set_debug): "queue_ppw", "queue_nbuf",
+    "queue_lds_pad", "grid_walk" (1 = nested item walk), "grid_spheres_per_cell"; 0 = the library's own choice."""
+    check(lib().apt_set_debug(key.encode(), ctypes.c_double(value)), "apt_set_debug")
+
+
+class debug_knob:
+    """with debug_knob("grid_walk", 1): ...  -- sets a knob of the default context and resets it to 0 on the way out, also after an
+    exception (tests select kernels this way, never through the process environment)."""
+
+    def __init__(self, key, value):
+        self.key, self.value = key, value
+
+    def __enter__(self):
+        set_debug(self.key, self.value)
+        return self
+
+    def __exit__(self, *exc):
+        set_debug(self.key, 0)
+
+
+def check_device_status(stream=None):
+    """apt_check: waits for `stream` (None = torch's current stream) and raises AptError when a kernel launched through the default
+    context reported a failure through the device status word since the last check (a tripped loop bound: the frame is incomplete)."""
+    require_gpu()
+    check(lib().apt_check(_stream_handle(stream)), "apt_check")
 
 
 def render_do_ex(params: RenderParams, stream, rays, spheres, colors):
@@ -316,14 +352,21 @@ def render_reference_frame_fused(w, h, s, depth=5, seed=0, spheres=None, mode=No
     npix = w * h
     if pixel_count is None:
         pixel_count = npix - pixel_begin
-    if checkpoints is None:
-        ck, g_lo = mt_group_checkpoints(w, h, s, seed, pixel_begin, pixel_count, mt_state)
-        checkpoints = (torch.from_numpy(ck.view(np.int32)).cuda(), g_lo)
-    ck_d, g_lo = checkpoints
-    p = make_params(w, h, s, depth=depth, mode=APT_MODE_ORACLE if mode is None else mode, flags=flags)
-    fb = torch.empty((3, pixel_count), dtype=torch.float32, device="cuda")
-    u8 = torch.empty((pixel_count, 3), dtype=torch.uint8, device="cuda")
-    check(lib().apt_render_frame_mt(ctypes.byref(p), _stream_handle(stream), ctypes.c_void_p(ck_d.data_ptr()), ctypes.c_uint64(ck_d.shape[0]),
+    # Everything this call allocates -- the generator states it uploads, the frame buffers -- is allocated and filled ON the stream the
+    # kernel runs on (a caller's side stream included), so the upload is ordered before the launch and the caching allocator does not
+    # hand the table to another stream while the kernel still reads it (the cross-stream lifetime hazard fixed for
+    # render_reference_frame in round 3).
+    tstream = torch.cuda.current_stream() if stream is None else (torch.cuda.ExternalStream(stream) if isinstance(stream, int) else stream)
+    with torch.cuda.stream(tstream):
+        if checkpoints is None:
+            ck, g_lo = mt_group_checkpoints(w, h, s, seed, pixel_begin, pixel_count, mt_state)
+            checkpoints = (torch.from_numpy(ck.view(np.int32)).cuda(), g_lo)
+        ck_d, g_lo = checkpoints
+        ck_d.record_stream(tstream)              # a caller's table made on another stream: keep it alive for this launch
+        p = make_params(w, h, s, depth=depth, mode=APT_MODE_ORACLE if mode is None else mode, flags=flags)
+        fb = torch.empty((3, pixel_count), dtype=torch.float32, device="cuda")
+        u8 = torch.empty((pixel_count, 3), dtype=torch.uint8, device="cuda")
+    check(lib().apt_render_frame_mt(ctypes.byref(p), _stream_handle(tstream), ctypes.c_void_p(ck_d.data_ptr()), ctypes.c_uint64(ck_d.shape[0]),
                                     ctypes.c_uint64(g_lo), _dev_f32(spheres, "spheres"), ctypes.c_uint64(pixel_begin),
                                     ctypes.c_uint64(pixel_count), ctypes.c_void_p(fb.data_ptr()), ctypes.c_void_p(u8.data_ptr())),
           "apt_render_frame_mt")

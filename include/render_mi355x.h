@@ -39,7 +39,13 @@
 extern "C" {
 #endif
 
-#define APT_ABI_VERSION 2
+/* librender_mi355x.so is built with -fvisibility=hidden and an export list (csrc/apt_exports.map): what this header declares --
+ * and the C++-mangled render_do of src/main.cpp:9-10 -- is all it exports. */
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
+
+#define APT_ABI_VERSION 3
 
 /* status codes returned by the *_ex / frame entry points (render_do itself is void,
  * like the reference, and reports through apt_last_status() / apt_last_error()). */
@@ -48,7 +54,8 @@ enum {
     APT_ERR_ARG = 1,       /* null pointer, zero size, size not representable            */
     APT_ERR_STRUCT = 2,    /* struct_size does not match this library                    */
     APT_ERR_SCENE = 3,     /* num_spheres == 0 or light_index out of range               */
-    APT_ERR_DEVICE = 4,    /* HIP runtime error (no device, launch failure, ...)         */
+    APT_ERR_DEVICE = 4,    /* HIP runtime error (no device, launch failure, ...), or a kernel  */
+                           /* reported a failure through the device status word (below)   */
     APT_ERR_IO = 5         /* file contract helpers                                      */
 };
 
@@ -141,7 +148,8 @@ int apt_set_default_params(const apt_render_params *p);
  * (24*N, 512 (padded table) and 12*N bytes for the default context's parameters), copies them to device 0's
  * current device, renders, copies the colours back and returns when they are there.  Allocates and frees its
  * device buffers; not capture-safe.  Whole frames only, like the reference's call: APT_ERR_ARG when the default
- * parameters carry a path sub-range.  (The arithmetic still runs on the GPU: there is no CPU path.) */
+ * parameters carry a strict path sub-range (path_begin != 0, or a path_count that is neither 0 nor N).  Checks the device
+ * status word before it returns.  (The arithmetic still runs on the GPU: there is no CPU path.) */
 int apt_render_host(uint32_t blockDim, const uint8_t *rays, const uint8_t *spheres, uint8_t *colors);
 
 /* ---- contexts: per-caller settings instead of process-wide ones ---------------------------------
@@ -153,6 +161,32 @@ void apt_context_destroy(apt_context *ctx);
 int  apt_context_set_params(apt_context *ctx, const apt_render_params *p);
 int  apt_context_set_trace_counter(apt_context *ctx, uint64_t *device_counter);
 int  apt_context_set_refill_lanes(apt_context *ctx, uint32_t lanes);
+
+/* Device-side failure channel (the reference asserts INSIDE its kernel: src/render.cpp:68-73 DataFormatCheck / ASSERT).  Every context
+ * owns one uint32 status word per device it has launched on; a kernel that has to give up ORs a bit into it (APT_DEV_*), and the frame
+ * it wrote is then incomplete.  The word is STICKY: it keeps every failure since the last check.
+ *   apt_context_check(ctx, stream)  waits for `stream` (synchronising; not capture-safe), reads the word of the current device and
+ *       clears it: APT_OK, or APT_ERR_DEVICE with the bits named in apt_last_error().  apt_check(stream) = the default context.
+ *   apt_render_host and apt_multi_render check it themselves before they return.
+ * The word is allocated on a context's first launch on a device (one hipMalloc of 4 bytes, once; skipped while `stream` is being
+ * captured -- a context whose FIRST launch on a device happens inside a graph capture runs without the word until a launch or an
+ * apt_context_check outside a capture has made it). */
+enum {
+    APT_DEV_QUEUE_GUARD = 1u,  /* sample-queue kernel (APT_FLAG_RETIRE, 8 spheres): the bound on a wave's loop turns ran out      */
+    APT_DEV_GRID_TURNS = 2u,   /* sample-queue kernel, grid form: the bound on a wave's walk turns ran out                         */
+    APT_DEV_LDS_BASE = 4u      /* sample-queue kernels: the dynamic LDS region does not start at LDS address 0 (a build problem)    */
+};
+int  apt_context_check(apt_context *ctx, void *stream);
+int  apt_check(void *stream);
+
+/* Measurement knobs of a context (0 = the library's own choice); tests and profiling scripts select kernels through these, never
+ * through the process environment (the APT_* variables of earlier rounds are read once, when a context is created, as initial values):
+ *   "queue_ppw" 1..4096 pixels per wave of the sample-queue kernels    "queue_nbuf" 2..16 colour buffers    "queue_lds_pad" bytes
+ *   "grid_walk" 1 = frames of a scene behind a grid use render_frame_kernel's nested item walk only (bit-identical, slower)
+ *   "grid_spheres_per_cell" cell size of apt_build_grid_host / apt_build_grid_device (default context's value)
+ * APT_ERR_ARG for an unknown key or a value out of range.  apt_set_debug = the default context. */
+int  apt_context_set_debug(apt_context *ctx, const char *key, double value);
+int  apt_set_debug(const char *key, double value);
 void apt_context_render_do(apt_context *ctx, uint32_t blockDim, void *l2ctrl, void *stream,
                            uint8_t *rays, uint8_t *spheres, uint8_t *colors);
 int  apt_context_render_do_ex(apt_context *ctx, const apt_render_params *p, void *stream,
@@ -332,6 +366,10 @@ const char *apt_last_error(void);       /* this thread's last call: "" when it s
 int         apt_last_status(void);      /* this thread's last call: APT_OK or APT_ERR_* (how a caller of the void
                                            render_do learns the outcome) */
 int         apt_device_count(void);     /* number of HIP devices, 0 when none */
+
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 
 #ifdef __cplusplus
 }

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Traced-segment counter of one frame by four routes: the oracle, the sample-queue kernel's grid form, the nested item walk
-(APT_GRID_WALK=items) and the brute-force traversal over LDS tiles, for sample counts with and without an n % 8 tail.  (Found in
+(the "grid_walk" knob) and the brute-force traversal over LDS tiles, for sample counts with and without an n % 8 tail.  (Found in
 round 3: with a tail the frame kernels counted the re-traced first tail sample of the lanes past the tail; fixed in pt_kernels.h.)
     python profiles/debug/qg_count.py"""
 import os, sys
@@ -19,10 +19,8 @@ for (w, h, s_, depth) in ((12, 8, 8, 6), (9, 7, 20, 5), (9, 7, 16, 5), (9, 7, 24
     _, _, _, tw = oracle.render_frame(op, scene, threads=8)
     with render.TraceCounter() as tq:
         render.render_frame(p.copy(accel=grid.data_ptr()), d_scene)
-    os.environ["APT_GRID_WALK"] = "items"
-    with render.TraceCounter() as tn:
+    with render.debug_knob("grid_walk", 1), render.TraceCounter() as tn:
         render.render_frame(p.copy(accel=grid.data_ptr()), d_scene)
-    del os.environ["APT_GRID_WALK"]
     with render.TraceCounter() as tb:
         render.render_frame(p, d_scene)
     print(w, h, s_, depth, "oracle", int(tw), "queue", tq.value, "nested", tn.value, "tiles", tb.value, flush=True)

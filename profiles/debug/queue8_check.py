@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Round 3: the rewritten sample-queue kernel (pt_queue.h) -- correctness against the oracle on small frames (frame bits and
-traced-segment counts), then C2 / C5 / C5 with roulette timed against the pixels-per-wave knob and against the round-2 queue
-(APT_OLD_QUEUE=1).   python profiles/debug/queue8_check.py [--skip-check] > gpurun_out/queue8.jsonl"""
+traced-segment counts), then C2 / C5 / C5 with roulette timed against the pixels-per-wave knob.  (Round 3 also timed the round-2
+queue here, through APT_OLD_QUEUE=1; that kernel was removed in round 4 -- profiles/r03_queue_check.jsonl keeps its numbers.)   python profiles/debug/queue8_check.py [--skip-check] > gpurun_out/queue8.jsonl"""
 import argparse, json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
@@ -29,7 +29,7 @@ if not args.skip_check:
         flags = apt.APT_FLAG_RETIRE | (apt.APT_FLAG_RR if rr else 0)
         oflags = oracle.FLAG_RETIRE | (oracle.FLAG_RR if rr else 0)
         for ppw in (1, 3, 16):
-            os.environ["APT_QUEUE_PPW"] = str(ppw)
+            render.set_debug("queue_ppw", ppw)
             for (b, c) in ((0, w * h), (min(3, w * h - 1), min(7, w * h - min(3, w * h - 1)))):
                 p = apt.make_params(w, h, s, depth=d, mode=mode, flags=flags, seed=5)
                 with render.TraceCounter() as tc:
@@ -64,12 +64,8 @@ for d, name in ((8, "c2_full"), (32, "c5_full")):
     fbf, u8f = render.render_frame(p, sph)
     full[name + "_fb"] = fbf
 print(json.dumps({k: v for k, v in full.items() if not k.endswith("_fb")}), flush=True)
-for ppw in ["old"] + [int(x) for x in args.ppw.split(",")]:
-    if ppw == "old":
-        os.environ["APT_OLD_QUEUE"] = "1"
-    else:
-        os.environ.pop("APT_OLD_QUEUE", None)
-        os.environ["APT_QUEUE_PPW"] = str(ppw)
+for ppw in [int(x) for x in args.ppw.split(",")]:
+    render.set_debug("queue_ppw", ppw)
     out = {"ppw": ppw}
     for d, flags, name in cases:
         p = apt.make_params(1920, 1080, 64, depth=d, flags=flags)

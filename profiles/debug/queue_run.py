@@ -41,15 +41,15 @@ for d in (1, 2, 3, 4, 8):
     print(json.dumps(out), flush=True)
 # occupancy sensitivity: extra LDS per wave
 for pad in (0, 2048, 4096, 8192, 16384):
-    os.environ["APT_QUEUE_LDS_PAD"] = str(pad)
+    render.set_debug("queue_lds_pad", pad)
     out = {"lds_pad": pad}
     for case in ("c2_retire", "c5_retire"):
         d, flags = CASES[case]
         out[case] = timeit(apt.make_params(1920, 1080, 64, depth=d, flags=flags), a.reps)
     print(json.dumps(out), flush=True)
-os.environ.pop("APT_QUEUE_LDS_PAD")
+render.set_debug("queue_lds_pad", 0)
 for nbuf in (2, 3, 4):
-    os.environ["APT_QUEUE_NBUF"] = str(nbuf)
+    render.set_debug("queue_nbuf", nbuf)
     out = {"nbuf": nbuf}
     for case in ("c2_retire", "c5_retire"):
         d, flags = CASES[case]

@@ -29,3 +29,14 @@ def oracle():
     from oracle import oracle as o
     o.lib()
     return o
+
+
+@pytest.fixture(autouse=True)
+def _device_status_is_clean(request):
+    """After every GPU test: no kernel launched through the default context may have reported a failure through the device
+    status word (a tripped loop bound of the sample-queue kernels: the reference asserts inside its kernel, src/render.cpp:68-73)."""
+    yield
+    if request.node.get_closest_marker("gpu") is None:
+        return
+    from ascendpathtracing_amd import render
+    render.check_device_status()

@@ -155,7 +155,7 @@ def test_c4_ten_thousand_spheres(apt):
 
 
 @pytest.mark.gpu
-def test_c4_whole_1080p_frame_three_traversals_agree(apt, monkeypatch):
+def test_c4_whole_1080p_frame_three_traversals_agree(apt):
     """Every pixel of the real C4 frame (10 000 spheres, 1080p, 256 spp): the sample-queue kernel's grid form (with and without
     retirement), the nested item walk and the brute-force traversal over LDS tiles give the same floats and bytes (the oracle
     pins 128 ranges of it above; a CPU pass over the whole frame would take hours)."""
@@ -164,9 +164,8 @@ def test_c4_whole_1080p_frame_three_traversals_agree(apt, monkeypatch):
     sph, ns, grid = _scene(apt, case, torch)
     fb_q, u8_q = apt.render.render_frame(_params(apt, case, ns, accel=grid.data_ptr()), sph)
     fb_r, u8_r = apt.render.render_frame(_params(apt, case, ns, accel=grid.data_ptr(), flags=apt.APT_FLAG_RETIRE), sph)
-    monkeypatch.setenv("APT_GRID_WALK", "items")
-    fb_n, u8_n = apt.render.render_frame(_params(apt, case, ns, accel=grid.data_ptr()), sph)
-    monkeypatch.delenv("APT_GRID_WALK")
+    with apt.render.debug_knob("grid_walk", 1):
+        fb_n, u8_n = apt.render.render_frame(_params(apt, case, ns, accel=grid.data_ptr()), sph)
     fb_b, u8_b = apt.render.render_frame(_params(apt, case, ns), sph)            # brute force: ~11 s
     torch.cuda.synchronize()
     for name, (f, u) in {"retire": (fb_r, u8_r), "nested": (fb_n, u8_n), "brute force": (fb_b, u8_b)}.items():

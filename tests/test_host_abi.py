@@ -32,7 +32,44 @@ def test_every_declared_symbol_is_exported(apt):
     for name in sorted(declared):
         assert hasattr(h, name), f"{name} declared in include/render_mi355x.h but not exported"
     assert set(apt._lib.ABI_SYMBOLS) == declared
-    assert h.apt_abi_version() == 2
+    assert h.apt_abi_version() == 3
+
+
+def test_the_library_exports_its_c_abi_and_nothing_else(apt):
+    """-fvisibility=hidden + csrc/apt_exports.map -- `nm -D --defined-only` shows the symbols the header declares
+    and the C++-mangled render_do of src/main.cpp:9-10, no context internals (apt_context::*, apt::default_context, apt::set_error)."""
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", apt._lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = {line.split()[-1] for line in out.splitlines() if line.strip()}
+    assert exported == set(apt._lib.ABI_SYMBOLS) | {apt._lib.CXX_RENDER_DO}, sorted(exported ^ (set(apt._lib.ABI_SYMBOLS) | {apt._lib.CXX_RENDER_DO}))
+    assert not [s_ for s_ in exported if s_.startswith("_ZN")]
+
+
+def test_no_launch_path_reads_the_process_environment(apt):
+    """getenv() appears once in the library -- where an apt_context is created (host_helpers.cpp) -- and in no
+    launch path (render_kernels.hip, the kernels' headers)."""
+    csrc = os.path.join(ROOT, "ascendpathtracing_amd", "csrc")
+    for f in os.listdir(csrc):
+        if f.endswith((".hip", ".h")) or f == "render_do_cxx.cpp":
+            src = re.sub(r"//.*", "", open(os.path.join(csrc, f)).read())
+            assert "getenv" not in src, f
+    body = re.sub(r"//.*", "", open(os.path.join(csrc, "host_helpers.cpp")).read())
+    ctor = body[body.index("double env_number"):body.index("apt_context::Values apt_context::snapshot()")]
+    assert body.count("getenv") == ctor.count("getenv") == 2
+
+
+def test_debug_knobs_argument_checks_without_a_gpu(apt):
+    lib = apt._lib.lib()
+    ctx = ctypes.c_void_p(lib.apt_context_create())
+    assert lib.apt_context_set_debug(ctx, b"queue_ppw", ctypes.c_double(16)) == 0
+    assert lib.apt_context_set_debug(ctx, b"queue_ppw", ctypes.c_double(0)) == 0
+    assert lib.apt_context_set_debug(ctx, b"grid_spheres_per_cell", ctypes.c_double(0.7)) == 0
+    for key, v in ((b"queue_ppw", 4097), (b"queue_ppw", 2.5), (b"queue_nbuf", 1), (b"queue_nbuf", 17), (b"grid_walk", 2), (b"nope", 1),
+                   (b"grid_spheres_per_cell", 0.001)):
+        assert lib.apt_context_set_debug(ctx, key, ctypes.c_double(v)) == 1 and lib.apt_last_status() == 1, (key, v)
+    assert lib.apt_context_set_debug(None, b"queue_ppw", ctypes.c_double(1)) == 1
+    assert lib.apt_context_set_debug(ctx, None, ctypes.c_double(1)) == 1
+    lib.apt_context_destroy(ctx)
 
 
 def test_params_struct_layout_matches_header(apt):
@@ -252,7 +289,7 @@ def test_header_is_plain_c_and_links_from_c(apt, tmp_path):
     subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"), str(src),
                     "-o", str(exe), "-L", libdir, "-lrender_mi355x", "-Wl,-rpath," + libdir], check=True)
     out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()
-    assert out == ["16", "16", "1", "5", "2", "272.25"]
+    assert out == ["16", "16", "1", "5", "3", "272.25"]
 
 
 # The reference's own declaration of the boundary, verbatim from src/main.cpp:9-10 (an interface, not code):
