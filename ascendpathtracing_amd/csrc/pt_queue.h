@@ -79,7 +79,9 @@ __host__ __device__ inline uint32_t queue_lds_bytes(bool rr, uint32_t nbuf, bool
 // per-bounce test of the flag.
 // SC == kScene8: the reference's 8 spheres (SGPR scene, fast bounce block).  SC == kSceneGrid: any scene through the pair-slot
 // tables of the uniform grid (apt_render_params.accel), every lane at its own place of its own walk: run_grid() below.
-template <int MODE, bool RR, int SC = kScene8>
+// STATS (grid form only): the per-lane walk statistics (cells visited, candidates tested) behind apt_set_trace_counter -- two registers and
+// two instructions per loop turn that a frame without a counter does not pay (the host picks the instantiation from ta.traced).
+template <int MODE, bool RR, int SC = kScene8, bool STATS = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SC == kSceneGrid ? APT_QUEUE_GRID_WAVES : APT_QUEUE8_WAVES, SC == kSceneGrid ? APT_QUEUE_GRID_WAVES : APT_QUEUE8_WAVES))) void render_frame_queue8_kernel(const float *__restrict__ sph, FrameArgs fa, TraceArgs ta,
                                                                  LeafProg lp, QueueArgs qa) {
     extern __shared__ __align__(16) unsigned char qlds[];
@@ -408,8 +410,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SC == kScene
 #ifdef APT_TEST_TINY_GUARD   // test build only (tests/test_gpu_boundary.py): the bound trips at once, the status word must say so
     uint32_t guard = 3u;
 #else
-    uint32_t guard = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)min(4ull * ((uint64_t)npx * 4u * S * ((uint64_t)ta.depth + 1u) + 64u), 0xffffffffull));
+    uint32_t guard = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)min(4ull * ((uint64_t)npx * 4u * S * ((uint64_t)ta.depth + 1u) + 64u), 0xfffffffeull));
 #endif
+    // A tripped bound is reported AFTER the loop, from the counter itself (`guard-- == 0u` leaves it at 0xffffffff, which no other exit can):
+    // the status pointer must not be live across the hot loop (it was, in the first form of this: 9-26 more spilled scalar registers, C2 with
+    // retirement 16.1 -> 17.7 ms, C4 180 -> 204).
+    constexpr uint32_t kGuardTripped = 0xffffffffu;
     auto run = [&](auto planes_tag) __attribute__((always_inline)) {
 #ifndef APT_QUEUE_JOIN_LOOP
         {
@@ -421,8 +427,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SC == kScene
             while (!finished) {
                 bool need_exact = false;
                 for (;;) {
-                    if (service(s)) { finished = true; break; }
-                    if (__builtin_expect(guard-- == 0u, 0)) { report_status(ta, APT_DEV_QUEUE_GUARD); finished = true; break; }
+                    if (service(s) || guard-- == 0u) { finished = true; break; }
                     Bounce8Mid mid;
                     bool redo_any = !fast_ok;
                     if (__builtin_expect(fast_ok, 1)) {
@@ -454,8 +459,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SC == kScene
         }
 #else   // (measurement: fast and exact arm of the bounce joined inside one loop, step() above)
         for (;;) {
-            if (service(s)) break;
-            if (__builtin_expect(guard-- == 0u, 0)) { report_status(ta, APT_DEV_QUEUE_GUARD); break; }
+            if (service(s) || guard-- == 0u) break;
             step(s, planes_tag);
         }
 #endif
@@ -531,6 +535,24 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SC == kScene
             }
             const uint64_t ka = root_pair<0>(hp.b, q) + nbias2, kb = root_pair<1>(hp.b, q) + nbias2;   // intersect_ns8_v2's keys
             const uint32_t ma = min((uint32_t)ka, (uint32_t)(ka >> 32)), mb = min((uint32_t)kb, (uint32_t)(kb >> 32));
+#ifndef APT_GRID_OLD_TIES
+            // The slot's own winner first (equal keys inside a slot: the first candidate, it has the lower id), then ONE comparison with the
+            // running minimum: nearer -> take it (and void a recorded tie), equal -> record the tie, farther -> nothing.  (Round 3 compared
+            // both candidates with the running minimum in turn: 4 more vector instructions per slot.)
+            const bool isb = mb < ma;
+            const uint32_t m2 = isb ? mb : ma;
+            const uint32_t psel = pos + (isb ? 1u : 0u);
+            const bool take = m2 < bestk, tie = TIES && m2 == bestk;
+            if (TIES && __builtin_expect(__builtin_amdgcn_ballot_w64(tie && pend != kNoPos) != 0, 0)) {
+                if (tie && pend != kNoPos) {
+                    if (slot_ids[pend] < id_at(bestp)) bestp = pend;
+                    pend = kNoPos;
+                }
+            }
+            bestk = take ? m2 : bestk;
+            bestp = take ? psel : bestp;
+            if (TIES) pend = take ? kNoPos : (tie ? psel : pend);
+#else
             const bool eq_a = TIES && ma == bestk, eq_b = TIES && mb == bestk && !eq_a, tie = eq_a || eq_b;
             if (TIES && __builtin_expect(__builtin_amdgcn_ballot_w64(tie && pend != kNoPos) != 0, 0)) {
                 if (tie && pend != kNoPos) {
@@ -545,6 +567,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SC == kScene
             bestk = take_b ? mb : bestk;
             bestp = take_b ? pos + 1u : bestp;
             if (TIES) pend = (take_a || take_b) ? kNoPos : (tie ? pos + (eq_b ? 1u : 0u) : pend);
+#endif
         };
         auto fetch_range = [&]() __attribute__((always_inline)) {
             const uint32_t cs = cellslot[lin];
@@ -552,7 +575,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SC == kScene
             uint32_t cnt = cs & kGridSlotCountMax;
             if (cnt == kGridSlotCountMax) cnt = (cell_start[lin + 1] - cell_start[lin] + 1u) >> 1;   // a long list (clustered scenes)
             end = cur + 2u * cnt;
-            ++n_cells;
+            if (STATS) ++n_cells;
         };
         // ---- one turn of the walking lanes ----
         auto turn = [&]() __attribute__((always_inline)) {
@@ -587,7 +610,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SC == kScene
                     const float4 a = slot_geom[cur], c4 = slot_geom[cur + 1u];   // slot cur / 2: float4s 2 * slot and 2 * slot + 1
                     test_pair(a, c4, cur, std::true_type{});
                     cur += 2u;
-                    n_tests += 2;
+                    if (STATS) n_tests += 2;
                 }
             }
             walking &= ~__builtin_amdgcn_ballot_w64(stop);
@@ -667,7 +690,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SC == kScene
                         const float4 g = geom[k];
                         const float t = intersect_sphere(g.x, g.y, g.z, g.w, s.oxy.x, s.oxy.y, s.oz, s.dxy.x, s.dxy.y, s.dz, ta.eps);
                         if (t < tmin) { tmin = t; idx = k; }
-                        ++n_tests;
+                        if (STATS) ++n_tests;
                     }
                     bestk = f32_bits(tmin) - kbias;             // tmin is kMissT or an accepted root: its key is exact
                     bestp = kIdFlag | idx;
@@ -676,7 +699,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SC == kScene
                         f32x8 g8;
                         asm volatile("s_load_dwordx8 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(g8) : "s"(slot_geom + 2 * j) : "memory");
                         test_pair(make_float4(g8[0], g8[1], g8[2], g8[3]), make_float4(g8[4], g8[5], g8[6], g8[7]), 2 * j, std::false_type{});
-                        n_tests += 2;
+                        if (STATS) n_tests += 2;
                     }
                 }
                 if (unit) {
@@ -738,10 +761,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SC == kScene
                 transition(waiting);
                 if (active == 0) break;                         // nothing runs, nothing could be issued: everything is parked
             }
-            if (__builtin_expect(turns_left-- == 0u, 0)) { report_status(ta, APT_DEV_GRID_TURNS); break; }
+            if (turns_left-- == 0u) break;
             turn();
         }
-        if (ta.traced) {                                        // statistics: cells visited / candidates tested (grid_stats)
+        if (turns_left == ~0ull) report_status(ta, APT_DEV_GRID_TURNS);   // (only the bound's own exit leaves the counter there; see `guard`)
+        if (STATS && ta.traced) {                               // statistics: cells visited / candidates tested (grid_stats)
             unsigned long long c = n_cells, t = n_tests;
             for (int off = 32; off > 0; off >>= 1) { c += __shfl_xor(c, off, 64); t += __shfl_xor(t, off, 64); }
             if (lane == 0) { atomicAdd(ta.traced + 1, c); atomicAdd(ta.traced + 2, t); }
@@ -751,6 +775,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SC == kScene
     if (SC == kSceneGrid) run_grid();
     else if (sc.planes) run(std::true_type{});
     else run(std::false_type{});
+    if (SC != kSceneGrid && guard == kGuardTripped) report_status(ta, APT_DEV_QUEUE_GUARD);
     // No lane is active, the pool is empty and every unit has been generated: every item is parked.  (After a tripped loop bound the
     // sums below read items that were never parked: the frame is incomplete and the status word says so.)
     while (a_unit < U) accumulate_unit();

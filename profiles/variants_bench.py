@@ -12,7 +12,7 @@ import argparse, ctypes, hashlib, json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def child(name, path, reps):
+def child(name, path, reps, full_c4=False):
     import numpy as np
     import torch
     sys.path.insert(0, ROOT)
@@ -35,6 +35,7 @@ def child(name, path, reps):
         return p
 
     def run(p):
+        nonlocal sph
         rc = lib.render_frame(ctypes.byref(p), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream), ctypes.c_void_p(sph.data_ptr()),
                               ctypes.c_uint64(0), ctypes.c_uint64(npix), ctypes.c_void_p(fb.data_ptr()), ctypes.c_void_p(u8.data_ptr()))
         assert rc == 0, lib.apt_last_error()
@@ -66,19 +67,46 @@ def child(name, path, reps):
     out["c5_d32_rr_retire_ms_min_med"] = timeit(params(32, flags=3))
     out["c5_d32_rr_ms_min_med"] = timeit(params(32, flags=2))      # one path per lane, no queue
     out["c2_omode_retire_ms_min_med"] = timeit(params(8, flags=1, mode=1))
+    # C4: the 10 000-sphere scene behind the uniform grid (sample-queue kernel, grid form) at 64 spp, and the frame's hash (must not change)
+    ns = 10000
+    nfl = ctypes.c_size_t(0)
+    assert lib.apt_gen_scene_host(ctypes.c_uint32(ns), ctypes.c_uint64(1), None, ctypes.byref(nfl)) == 0
+    scene_h = np.zeros(nfl.value, dtype=np.float32)
+    assert lib.apt_gen_scene_host(ctypes.c_uint32(ns), ctypes.c_uint64(1), scene_h.ctypes.data_as(ctypes.c_void_p), ctypes.byref(nfl)) == 0
+    nby = ctypes.c_size_t(0)
+    assert lib.apt_build_grid_host(scene_h.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint32(ns), None, ctypes.byref(nby)) == 0
+    grid_h = np.zeros(nby.value // 4, dtype=np.uint32)
+    assert lib.apt_build_grid_host(scene_h.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint32(ns), grid_h.ctypes.data_as(ctypes.c_void_p), ctypes.byref(nby)) == 0
+    scene, grid = torch.from_numpy(scene_h).cuda(), torch.from_numpy(grid_h.view(np.int32)).cuda()
+    sph_saved = sph
+
+    def params4(s4, flags=0):
+        p = params(8, flags=flags)
+        p.samples, p.num_spheres, p.light_index, p.accel = s4, ns, ns - 1, grid.data_ptr()
+        return p
+    sph = scene                      # run() reads `sph`
+    for s4, key in ((16, "c4_grid_s16"), (64, "c4_grid_s64")):
+        if s4 == 64 and not full_c4:
+            continue
+        out[key + "_ms_min_med"] = timeit(params4(s4))
+        out[key + "_retire_ms_min_med"] = timeit(params4(s4, flags=1))
+    run(params4(16)); torch.cuda.synchronize()
+    out["c4_grid_s16_u8_sha"] = hashlib.sha256(u8.cpu().numpy().tobytes()).hexdigest()[:16]
+    sph = sph_saved
     print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "--child":
-        child(sys.argv[2], sys.argv[3], int(sys.argv[4]))
+        child(sys.argv[2], sys.argv[3], int(sys.argv[4]), full_c4=len(sys.argv) > 5 and sys.argv[5] == "1")
         sys.exit(0)
     ap = argparse.ArgumentParser()
     ap.add_argument("libs", nargs="+")
     ap.add_argument("--reps", type=int, default=7)
+    ap.add_argument("--full-c4", action="store_true", help="also time C4 at its full 256 spp (S = 64: ~0.2 s per frame)")
     a = ap.parse_args()
     for spec in a.libs:
         name, path = spec.split("=", 1)
-        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", name, os.path.abspath(path), str(a.reps)])
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", name, os.path.abspath(path), str(a.reps), "1" if a.full_c4 else "0"])
         if r.returncode:
             print(json.dumps({"lib": name, "error": r.returncode}), flush=True)
