@@ -496,6 +496,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SC == kScene
         const float4 *slot_geom = reinterpret_cast<const float4 *>(grid + h.off_slots);
         const float4 *sphere8 = reinterpret_cast<const float4 *>(grid + h.off_sphere8);
         const int miss = (MODE == kModeOracle) ? -1 : 0;
+        // The first kBigLds pair slots of the always-tested list live in LDS (the 8-sphere table's place, unused in this form): every segment
+        // start reads them with uniform-address ds_read_b128 broadcasts, all issued before the first test.  Round 3 fetched each slot with a
+        // scalar load and waited for it, four dependent memory latencies per segment start: re-running the list (measurement build,
+        // profiles/r04_grid_ablation.jsonl) showed that one pass cost 46 % of the C4 frame, five times its instruction share.  Pairs beyond
+        // kBigLds (more than 8 large spheres) keep the scalar loads.  Unused LDS pairs hold NaN spheres: a NaN discriminant is never a hit.
+        constexpr uint32_t kBigLds = 4;
+        static_assert(2 * kBigLds <= (uint32_t)kTab8Floats4, "the LDS copy uses the 8-sphere table's region");
+        if (lane < 2u * kBigLds) {
+            const float qn = __uint_as_float(0x7fc00000u);
+            tab[lane] = lane < 2u * min(h.slot_base, kBigLds) ? slot_geom[lane] : make_float4(qn, qn, qn, qn);
+        }
+        __syncthreads();
         // root keys (pt_trace.h KeyConsts), wave-uniform here: scalar registers
         const uint32_t kbias = f32_bits(ta.eps) + 1u, kinit = f32_bits(kMissT) - kbias;
         const uint64_t nbias2 = ((uint64_t)(0u - kbias) << 32) | (0x80000000u - kbias);
@@ -569,6 +581,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SC == kScene
             if (TIES) pend = (take_a || take_b) ? kNoPos : (tie ? pos + (eq_b ? 1u : 0u) : pend);
 #endif
         };
+        // cellslot[lin] -> the cell's POSITION range [cur, end) in the pair-slot tables
         auto fetch_range = [&]() __attribute__((always_inline)) {
             const uint32_t cs = cellslot[lin];
             cur = (cs >> kGridSlotCountBits) << 1;
@@ -621,35 +634,70 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SC == kScene
             ++n_bounce_exec;
             const uint64_t fin = batch & has_seg & active;     // lanes whose finished segment is shaded now
             traced += (uint32_t)__popcll(fin);
+            bool is_light = false;                             // (wave masks are only formed outside divergent regions)
+            Albedo alb = {f2{1.0f, 1.0f}, 1.0f};
             if (lane_in(fin)) {
                 const float tmin = bits_f32(bestk + kbias);
-                int idx = miss;
-                if (bestk != kinit) {
-                    uint32_t id = id_at(bestp);
-                    if (pend != kNoPos) { const uint32_t idp = slot_ids[pend]; id = idp < id ? idp : id; }   // a recorded tie: the lower index wins
-                    idx = (int)id;
+                // What the shading step needs of the winner: its centre -- straight from the winner's own pair slot, no sphere index needed --
+                // and its index (light test, albedo), requested TOGETHER: one memory latency; the albedo (one more, it needs the index) is
+                // only used after the reflection.  (Round 3: index -> sphere8 record -> shading, two latencies in front of the arithmetic.)
+                const bool hit = bestk != kinit, by_pos = hit && !(bestp & kIdFlag);
+                float cx = 0.0f, cy = 0.0f, cz = 0.0f;
+                uint32_t id = bestp & ~kIdFlag;
+                if (by_pos) {
+                    const float *sg = reinterpret_cast<const float *>(slot_geom) + 8 * (size_t)(bestp >> 1) + (bestp & 1u);
+                    id = slot_ids[bestp];
+                    cx = sg[0]; cy = sg[2]; cz = sg[4];
+                    if (__builtin_expect(pend != kNoPos, 0)) {   // a recorded tie: the lower index wins (nearly always the same sphere again)
+                        const uint32_t idp = slot_ids[pend];
+                        if (idp < id) {
+                            const float *sp = reinterpret_cast<const float *>(slot_geom) + 8 * (size_t)(pend >> 1) + (pend & 1u);
+                            id = idp;
+                            cx = sp[0]; cy = sp[2]; cz = sp[4];
+                        }
+                    }
                 }
+                const int idx = hit ? (int)id : miss;
                 const uint32_t g = (idx < 0) ? ns - 1 : (uint32_t)idx;
-                const float4 gc = sphere8[2 * (size_t)g], col = sphere8[2 * (size_t)g + 1];   // centre, r2 | albedo: one cache line
-                PathState c = s, n;
-                c.rxy = thr_xy; c.rz = thr_z; c.alive = select_const(alive, 1);
-                n = c;
-                float amin = 1.0f;
-                shade_and_reflect<MODE, true>(n, tmin, gc.x, gc.y, gc.z, col.x, col.y, col.z, idx == ta.light, &amin);
-                if (__builtin_expect(__builtin_amdgcn_ballot_w64(amin < 0x1p-96f) != 0, 0)) {   // out of the fast sequences' range: sqrtf() and '/'
-                    asm volatile("" ::: "memory");
-                    n = c;
-                    shade_and_reflect<MODE>(n, tmin, gc.x, gc.y, gc.z, col.x, col.y, col.z, idx == ta.light);
+                if (!by_pos) { const float4 gcf = sphere8[2 * (size_t)g]; cx = gcf.x; cy = gcf.y; cz = gcf.z; }   // all-miss, or a lane that tested every sphere
+                const float4 gc = make_float4(cx, cy, cz, 0.0f), col = sphere8[2 * (size_t)g + 1];   // albedo
+                is_light = idx == ta.light;
+                alb = Albedo{f2{col.x, col.y}, col.z};
+                // GenerateNewRays in the packed form of the 8-sphere kernel's bounce (pt_trace.h reflect_packed: 2 operations per instruction for
+                // the x / y components); outside the fast sequences' range the step is redone with sqrtf() and '/'
+                PathState n;
+                const float amin = reflect_packed<MODE>(s, tmin, gc.x, gc.y, gc.z, n);
+#ifdef APT_ABL_SHADE2   // measurement only (same image): the reflection computed twice
+                {
+                    PathState n2;
+                    float t2 = tmin;
+                    asm volatile("" : "+v"(t2));
+                    const float a2 = reflect_packed<MODE>(s, t2, gc.x, gc.y, gc.z, n2);
+                    asm volatile("" :: "v"(a2), "v"(n2.oxy), "v"(n2.oz), "v"(n2.dxy), "v"(n2.dz));
                 }
-                if (rr) {
-                    const uint32_t d = ta.depth - 1u - left;
-                    if (d + 1u >= ta.rr_start) russian_roulette(n, key, d);
+#endif
+                if (__builtin_expect(__builtin_amdgcn_ballot_w64(!(amin >= kFastMin)) != 0, 0)) {
+                    asm volatile("" ::: "memory");
+                    PathState c = s;
+                    c.rxy = thr_xy; c.rz = thr_z; c.alive = 1u;
+                    shade_and_reflect<MODE>(c, tmin, gc.x, gc.y, gc.z, col.x, col.y, col.z, is_light);
+                    n.oxy = c.oxy; n.oz = c.oz; n.dxy = c.dxy; n.dz = c.dz;
                 }
                 s.oxy = n.oxy; s.oz = n.oz; s.dxy = n.dxy; s.dz = n.dz;
-                thr_xy = n.rxy; thr_z = n.rz;
-                s.alive = n.alive;
             }
-            alive = (alive & ~fin) | (fin & __builtin_amdgcn_ballot_w64(s.alive != 0));
+            // AccumulateIntervalColor (rt_helper.h:711-830): alive &= idx != light; ret *= alive ? albedo : 1 -- the product under exec = the
+            // lanes of `fin` still alive after this bounce
+            alive &= ~(fin & __builtin_amdgcn_ballot_w64(is_light));
+            apply_albedo(thr_xy, thr_z, alb, alive & fin);
+            if (rr) {
+                const uint32_t d = ta.depth - 1u - left;
+                if (lane_in(fin) && d + 1u >= ta.rr_start) {
+                    PathState t;
+                    t.rxy = thr_xy; t.rz = thr_z; t.alive = select_const(alive, 1);
+                    russian_roulette(t, key, d);
+                    thr_xy = t.rxy; thr_z = t.rz;
+                }
+            }
             {   // park the finished paths of `fin` (park() of the 8-sphere form, restricted to these lanes)
                 uint64_t zero, at_depth, saved;
                 uint32_t orbits;
@@ -695,49 +743,93 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SC == kScene
                     bestk = f32_bits(tmin) - kbias;             // tmin is kMissT or an accepted root: its key is exact
                     bestp = kIdFlag | idx;
                 } else {
-                    for (uint32_t j = 0; j < h.slot_base; ++j) {    // the always-tested list: wave-uniform addresses, scalar loads
-                        f32x8 g8;
-                        asm volatile("s_load_dwordx8 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(g8) : "s"(slot_geom + 2 * j) : "memory");
-                        test_pair(make_float4(g8[0], g8[1], g8[2], g8[3]), make_float4(g8[4], g8[5], g8[6], g8[7]), 2 * j, std::false_type{});
-                        if (STATS) n_tests += 2;
+#ifdef APT_ABL_LARGE2   // measurement only (same image): the always-tested list evaluated twice -- the time difference is what one pass costs
+                    for (int rep = 0; rep < 2; ++rep)
+#endif
+                    {
+                        // the always-tested list: its first kBigLds pair slots from LDS (uniform addresses: broadcasts, all in flight together;
+                        // pads are NaN spheres), the rest -- scenes with more than 2 * kBigLds large spheres -- by scalar loads
+                        float4 big[2 * kBigLds];
+#pragma unroll
+                        for (uint32_t j = 0; j < 2u * kBigLds; ++j) big[j] = tab[j];
+#pragma unroll
+                        for (uint32_t j = 0; j < kBigLds; ++j) {
+                            if (j < h.slot_base) {                  // wave-uniform
+                                test_pair(big[2 * j], big[2 * j + 1], 2 * j, std::false_type{});
+                                if (STATS) n_tests += 2;
+                            }
+                        }
+                        for (uint32_t j = kBigLds; j < h.slot_base; ++j) {
+                            f32x8 g8;
+                            asm volatile("s_load_dwordx8 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(g8) : "s"(slot_geom + 2 * j) : "memory");
+                            test_pair(make_float4(g8[0], g8[1], g8[2], g8[3]), make_float4(g8[4], g8[5], g8[6], g8[7]), 2 * j, std::false_type{});
+                            if (STATS) n_tests += 2;
+                        }
                     }
                 }
                 if (unit) {
-                    float tn = 0.0f, tf = 3.0e38f;
-                    bool inbox = true;
+                    // DDA set-up.  The origin of every segment but a path's first lies on a sphere's surface, and in a closed room that is
+                    // inside the grid box (so do the camera's ray origins in the demo scenes): the cell of the origin is where the walk
+                    // starts, and whether the origin IS in the box comes out of the cell computation itself (0 <= cell < n, unsigned).  Only
+                    // when some starting lane's origin lies outside (wave-level, rare) does the slab test decide where -- whether -- its ray
+                    // enters the box (round 3 ran slab test, entry point and clamps for every segment: ~55 of this block's vector instructions).
                     const float ix = __builtin_amdgcn_rcpf(s.dxy.x), iy = __builtin_amdgcn_rcpf(s.dxy.y), iz = __builtin_amdgcn_rcpf(s.dz);
-                    auto slab = [&](float o, float dv, float inv, float lo, float hi) __attribute__((always_inline)) {
-                        if (fabsf(dv) > 1e-20f) {
-                            const float t1 = (lo - o) * inv, t2 = (hi - o) * inv;
-                            tn = fmaxf(tn, fminf(t1, t2));
-                            tf = fminf(tf, fmaxf(t1, t2));
-                        } else if (!(o >= lo && o <= hi)) inbox = false;
+                    const int n0 = (int)h.n[0], n1 = (int)h.n[1], n2 = (int)h.n[2];
+                    const float e0 = s.oxy.x - h.gmin[0], e1 = s.oxy.y - h.gmin[1], e2 = s.oz - h.gmin[2];   // origin relative to the box corner
+                    auto cell_of = [](float f) __attribute__((always_inline)) -> int {   // floor + convert in one instruction (saturating; NaN -> 0)
+                        int c;
+                        asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(c) : "v"(f));
+                        return c;
                     };
-                    slab(s.oxy.x, s.dxy.x, ix, h.gmin[0], h.gmax[0]);
-                    slab(s.oxy.y, s.dxy.y, iy, h.gmin[1], h.gmax[1]);
-                    slab(s.oz, s.dz, iz, h.gmin[2], h.gmax[2]);
-                    if (inbox && tn <= tf) {
-                        auto axis = [&](float o, float dv, float inv, float lo, float cellw, float invw, int na, int stride, int &c, int &inc,
-                                        uint32_t &steps, float &tmax, float &tdel) __attribute__((always_inline)) {
-                            int ci = (int)floorf((o + dv * tn - lo) * invw);
-                            ci = ci < 0 ? 0 : (ci >= na ? na - 1 : ci);
-                            c = ci;
-                            // one form for both directions: the boundary ahead is plane ci + 1 (dv > 0) or ci (dv < 0), and -cellw * inv = cellw * |inv|
-                            const bool fwd = dv > 0.0f, moves = fabsf(dv) > 1e-20f;
-                            const float t_b = (lo + (float)(ci + (fwd ? 1 : 0)) * cellw - o) * inv;
-                            tmax = moves ? t_b : 3.0e38f;                     // (an axis that does not move is never the nearest crossing of a unit
-                            tdel = moves ? cellw * fabsf(inv) : 3.0e38f;      //  direction within kMissT)
-                            inc = moves ? (fwd ? stride : -stride) : 0;
-                            steps = moves ? (uint32_t)(fwd ? na - 1 - ci : ci) : 0u;
+                    int c0 = cell_of(e0 * h.inv_cell[0]), c1 = cell_of(e1 * h.inv_cell[1]), c2 = cell_of(e2 * h.inv_cell[2]);
+                    const bool inside = (uint32_t)c0 < (uint32_t)n0 && (uint32_t)c1 < (uint32_t)n1 && (uint32_t)c2 < (uint32_t)n2;
+                    bool go = true;
+                    float tn = 0.0f;
+                    if (__builtin_expect(__builtin_amdgcn_ballot_w64(!inside) != 0, 0)) {
+                        asm volatile("" ::: "memory");
+                        float tf = 3.0e38f;
+                        bool inbox = true;
+                        auto slab = [&](float o, float dv, float inv, float lo, float hi) __attribute__((always_inline)) {
+                            if (fabsf(dv) > 1e-20f) {
+                                const float t1 = (lo - o) * inv, t2 = (hi - o) * inv;
+                                tn = fmaxf(tn, fminf(t1, t2));
+                                tf = fminf(tf, fmaxf(t1, t2));
+                            } else if (!(o >= lo && o <= hi)) inbox = false;
                         };
-                        int c0, c1, c2;
+                        slab(s.oxy.x, s.dxy.x, ix, h.gmin[0], h.gmax[0]);
+                        slab(s.oxy.y, s.dxy.y, iy, h.gmin[1], h.gmax[1]);
+                        slab(s.oz, s.dz, iz, h.gmin[2], h.gmax[2]);
+                        go = inbox && tn <= tf;
+                        auto entry_cell = [&](float e, float dv, float invw, int na) __attribute__((always_inline)) -> int {
+                            const int ci = (int)floorf((e + dv * tn) * invw);      // (an origin inside has tn = 0: the cell computed above)
+                            return ci < 0 ? 0 : (ci >= na ? na - 1 : ci);
+                        };
+                        c0 = entry_cell(e0, s.dxy.x, h.inv_cell[0], n0);
+                        c1 = entry_cell(e1, s.dxy.y, h.inv_cell[1], n1);
+                        c2 = entry_cell(e2, s.dz, h.inv_cell[2], n2);
+                    }
+                    if (go) {
+                        // per axis: the parameter of the boundary ahead -- plane ci + 1 (dv > 0) or ci (dv < 0) of the axis, relative to the
+                        // box corner like e --, the parameter step per cell (-cellw * inv = cellw * |inv| for dv < 0), the linear-index step
+                        // and the steps left.  An axis the ray does not move along gets a crossing that never comes first (it is never the
+                        // nearest crossing of a unit direction within kMissT), so its other values are never used.
+                        auto axis = [&](float e, float dv, float inv, float cellw, int ci, int na, int stride, int &inc, uint32_t &steps, float &tmax,
+                                        float &tdel) __attribute__((always_inline)) {
+                            const bool fwd = dv > 0.0f, moves = fabsf(dv) > 1e-20f;
+                            const float t_b = __builtin_fmaf((float)(ci + (fwd ? 1 : 0)), cellw, -e) * inv;
+                            tmax = moves ? t_b : 3.0e38f;
+                            tdel = moves ? cellw * fabsf(inv) : 3.0e38f;
+                            inc = fwd ? stride : -stride;
+                            steps = (uint32_t)(fwd ? na - 1 - ci : ci);
+                        };
                         uint32_t l0, l1, l2;
-                        const int n0 = (int)h.n[0], n1 = (int)h.n[1], n2 = (int)h.n[2];
-                        axis(s.oxy.x, s.dxy.x, ix, h.gmin[0], h.cell[0], h.inv_cell[0], n0, 1, c0, inc0, l0, tm0, td0);
-                        axis(s.oxy.y, s.dxy.y, iy, h.gmin[1], h.cell[1], h.inv_cell[1], n1, n0, c1, inc1, l1, tm1, td1);
-                        axis(s.oz, s.dz, iz, h.gmin[2], h.cell[2], h.inv_cell[2], n2, n0 * n1, c2, inc2, l2, tm2, td2);
+                        axis(e0, s.dxy.x, ix, h.cell[0], c0, n0, 1, inc0, l0, tm0, td0);
+                        axis(e1, s.dxy.y, iy, h.cell[1], c1, n1, n0, inc1, l1, tm1, td1);
+                        axis(e2, s.dz, iz, h.cell[2], c2, n2, n0 * n1, inc2, l2, tm2, td2);
                         lin = (uint32_t)((c2 * n1 + c1) * n0 + c0);
                         rem = kGuard | l0 | l1 << 10 | l2 << 20;
+                        // (Requesting this first range before the axis arithmetic and waiting after it -- inline-asm load -- was measured:
+                        // 52.5 against 44.7 ms at 64 spp; the asm's memory clobber doubled the spilled scalar registers.)
                         fetch_range();
                         walk = true;
                     }

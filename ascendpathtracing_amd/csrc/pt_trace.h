@@ -518,6 +518,62 @@ __device__ __forceinline__ void bounce_ns8_v2_reflect(PathState &s, const Bounce
     albedo = Albedo{f2{m.col.x, m.col.y}, m.col.z};
 }
 
+// The shading half of bounce_ns8_v2 for a hit given by value (nearest root tmin, centre of the hit sphere): GenerateNewRays
+// (rt_helper.h:504-709) with the x and y components of every 3-vector operation in one packed instruction, the single-rsq square root and
+// the shared-reciprocal divide.  Writes the new ray to n.oxy / n.oz / n.dxy / n.dz and returns the validity minimum of the fast sequences
+// (see kFastMin): the caller redoes a bounce whose minimum is not >= kFastMin with shade_and_reflect<MODE>() (sqrtf() and '/').
+// Operation for operation what shade_and_reflect<MODE, true>() computes for the ray.  (Grid form of the sample-queue kernel, pt_queue.h.)
+template <int MODE>
+__device__ __forceinline__ float reflect_packed(const PathState &s, float tmin, float cx, float cy, float cz, PathState &n) {
+    const f2 hxy = s.oxy + s.dxy * tmin;                       // :513-518  h = o + d*t (mul, then add)
+    const float hz = s.oz + s.dz * tmin;
+    const f2 nxy = hxy - f2{cx, cy};                           // :635-637
+    const float nz = hz - cz;
+    const f2 sq = nxy * nxy;
+    float len2;
+    if (MODE == kModeOracle) {                                 // np.linalg.norm, gen_data.py:347: float64 accumulation
+        const float p2 = nz * nz;
+        double acc = 0.0 + (double)sq.x;
+        acc = acc + (double)sq.y;
+        acc = acc + (double)p2;
+        len2 = (float)acc;
+    } else {
+        float acc = sq.x + sq.y;                               // :641-649 (0 + x^2 is x^2: a square is never -0)
+        acc = acc + nz * nz;
+        len2 = acc;
+    }
+    const float r0 = __builtin_amdgcn_rsqf(len2);
+    float amin = minimum3_abs_after_trans(1.0f, r0, nxy.x);    // validity of the fast sqrt / divide sequences: see kFastMin
+    amin = minimum3_abs(amin, nxy.y, nz);
+    float L;
+    {
+        const float y = len2 * r0, h = 0.5f * r0;
+        const float r = __builtin_fmaf(-y, y, len2);
+        L = __builtin_fmaf(r, h, y);
+    }
+    f2 uxy;
+    float uz;
+    div3_packed(nxy, nz, L, uxy, uz);
+    const f2 pr = s.dxy * uxy;
+    const float pz = s.dz * uz;
+    float dot;
+    if (MODE == kModeOracle) {                                 // np.dot, gen_data.py:349
+        double acc = 0.0 + (double)pr.x;
+        acc = acc + (double)pr.y;
+        acc = acc + (double)pz;
+        dot = (float)acc;
+    } else {
+        dot = 0.0f + pr.x;                                     // :690 Duplicate(0), :694-696
+        dot = dot + pr.y;
+        dot = dot + pz;
+    }
+    const float k2 = dot * 2.0f;                               // :697
+    n.dxy = s.dxy - uxy * k2;                                  // :699-704
+    n.dz = s.dz - uz * k2;
+    n.oxy = hxy; n.oz = hz;                                    // :706-708
+    return amin;
+}
+
 // The same with the plane-sharing form of the intersections chosen at run time (scene8_shares_planes(), wave-uniform)
 template <int MODE>
 __device__ __forceinline__ uint64_t bounce_ns8_v2p(const Scene8 &sc, const Tab8 tab, const PathState &s, PathState &n, const TraceArgs &ta,

@@ -229,13 +229,18 @@ int do_render_frame(const Launch &ls, const apt_render_params *p, void *stream, 
         size_t qlds;
         const bool rrk = ta.rr_start != 0;
         if (!queue_launch_shape(dbg, lp, rrk, pixel_count, retire, qa, waves, qlds)) return fail(APT_ERR_ARG, "pixel_count too large for one launch; shard it%s");
-        if (p->mode == APT_MODE_ORACLE) {
-            if (rrk) hipLaunchKernelGGL((render_frame_queue8_kernel<kModeOracle, true, kSceneGrid>), dim3((unsigned)waves), dim3(64), qlds, st, spheres, fa, ta, lp, qa);
-            else hipLaunchKernelGGL((render_frame_queue8_kernel<kModeOracle, false, kSceneGrid>), dim3((unsigned)waves), dim3(64), qlds, st, spheres, fa, ta, lp, qa);
+        // (the walk statistics behind apt_set_trace_counter are a template flag: a frame without a counter does not carry them)
+        const bool oracle = p->mode == APT_MODE_ORACLE, stats = ta.traced != nullptr;
+        const dim3 qgrid((unsigned)waves), qblock(64);
+#define APT_LAUNCH_GRID_QUEUE(M, R, S) hipLaunchKernelGGL((render_frame_queue8_kernel<M, R, kSceneGrid, S>), qgrid, qblock, qlds, st, spheres, fa, ta, lp, qa)
+        if (oracle) {
+            if (rrk) { if (stats) APT_LAUNCH_GRID_QUEUE(kModeOracle, true, true); else APT_LAUNCH_GRID_QUEUE(kModeOracle, true, false); }
+            else { if (stats) APT_LAUNCH_GRID_QUEUE(kModeOracle, false, true); else APT_LAUNCH_GRID_QUEUE(kModeOracle, false, false); }
         } else {
-            if (rrk) hipLaunchKernelGGL((render_frame_queue8_kernel<kModeKernel, true, kSceneGrid>), dim3((unsigned)waves), dim3(64), qlds, st, spheres, fa, ta, lp, qa);
-            else hipLaunchKernelGGL((render_frame_queue8_kernel<kModeKernel, false, kSceneGrid>), dim3((unsigned)waves), dim3(64), qlds, st, spheres, fa, ta, lp, qa);
+            if (rrk) { if (stats) APT_LAUNCH_GRID_QUEUE(kModeKernel, true, true); else APT_LAUNCH_GRID_QUEUE(kModeKernel, true, false); }
+            else { if (stats) APT_LAUNCH_GRID_QUEUE(kModeKernel, false, true); else APT_LAUNCH_GRID_QUEUE(kModeKernel, false, false); }
         }
+#undef APT_LAUNCH_GRID_QUEUE
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return hip_fail(e);
         ta_frame.grid_walk = 2;
