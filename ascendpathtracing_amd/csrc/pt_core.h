@@ -416,6 +416,21 @@ inline void camera_init(Camera &c, uint32_t w, uint32_t h) { // gen_data.py:24-3
     c.inv_h = 1.0 / (double)h;
 }
 
+// What camera_ray() reads of a Camera, and nothing else (80 bytes): the sample-queue kernels keep this form in LDS, where every byte counts
+// towards the occupancy (pt_queue.h).  camera_ray_t() reads either type through the accessors below.
+struct CameraLite { double cx0, cy1, cy2, g1, g2, pos[3], inv_w, inv_h; };
+APT_HD CameraLite camera_lite(const Camera &c) { return CameraLite{c.cx[0], c.cy[1], c.cy[2], c.g[1], c.g[2], {c.pos[0], c.pos[1], c.pos[2]}, c.inv_w, c.inv_h}; }
+APT_HD double cam_cx0(const Camera &c) { return c.cx[0]; }
+APT_HD double cam_cy1(const Camera &c) { return c.cy[1]; }
+APT_HD double cam_cy2(const Camera &c) { return c.cy[2]; }
+APT_HD double cam_g1(const Camera &c) { return c.g[1]; }
+APT_HD double cam_g2(const Camera &c) { return c.g[2]; }
+APT_HD double cam_cx0(const CameraLite &c) { return c.cx0; }
+APT_HD double cam_cy1(const CameraLite &c) { return c.cy1; }
+APT_HD double cam_cy2(const CameraLite &c) { return c.cy2; }
+APT_HD double cam_g1(const CameraLite &c) { return c.g1; }
+APT_HD double cam_g2(const CameraLite &c) { return c.g2; }
+
 #if defined(__HIP_DEVICE_COMPILE__)
 // float64 sqrt for ray-generate: the core of hipcc's own expansion (v_rsq_f64, coupled Goldschmidt
 // steps, two residual corrections) without its ldexp pre/post-scaling (only needed below 2^-767) and
@@ -499,8 +514,8 @@ __device__ __forceinline__ double refined_reciprocal(double b) {
 
 // Outputs are six scalar references on purpose: an aggregate result gets its stores merged into
 // vector stores to a stack slot that SROA can then no longer promote (it ended up in scratch).
-template <bool FAST>
-APT_HD bool camera_ray_t(const Camera &c, uint32_t w, uint32_t h, uint32_t i, uint32_t j, uint32_t sy, uint32_t sx,
+template <bool FAST, class CAM>
+APT_HD bool camera_ray_t(const CAM &c, uint32_t w, uint32_t h, uint32_t i, uint32_t j, uint32_t sy, uint32_t sx,
                          double u1, double u2, float &rox, float &roy, float &roz, float &rdx, float &rdy, float &rdz) {
     double arg1, arg2;
     const double ddx = tent_t<FAST>(u1, arg1), ddy = tent_t<FAST>(u2, arg2);
@@ -520,9 +535,9 @@ APT_HD bool camera_ray_t(const Camera &c, uint32_t w, uint32_t h, uint32_t i, ui
     // and g = (+0, g1, g2) (camera_init checks it).  The vanishing terms are exact identities, signs of zero
     // included: a = q - 0.5 is never -0, so cx0*a + (+-0) + (+0) is cx0*a bit for bit; (+-0 + cy1*b) + g1 with
     // g1 != 0 is cy1*b + g1.  Seven float64 operations per ray less than the general form the oracle keeps.
-    const double d0 = c.cx[0] * a;
-    const double d1 = c.cy[1] * b + c.g[1];
-    const double d2 = c.cy[2] * b + c.g[2];
+    const double d0 = cam_cx0(c) * a;
+    const double d1 = cam_cy1(c) * b + cam_g1(c);
+    const double d2 = cam_cy2(c) * b + cam_g2(c);
     const double n2 = norm3_sq(d0, d1, d2);
     rox = (float)(c.pos[0] + d0 * 140);                                      // :45
     roy = (float)(c.pos[1] + d1 * 140);
@@ -550,7 +565,8 @@ APT_HD bool camera_ray_t(const Camera &c, uint32_t w, uint32_t h, uint32_t i, ui
 
 // Outputs are six scalar references on purpose: an aggregate result gets its stores merged into
 // vector stores to a stack slot that SROA can then no longer promote (it ended up in scratch).
-APT_HD void camera_ray(const Camera &c, uint32_t w, uint32_t h, uint32_t i, uint32_t j, uint32_t sy, uint32_t sx,
+template <class CAM>
+APT_HD void camera_ray(const CAM &c, uint32_t w, uint32_t h, uint32_t i, uint32_t j, uint32_t sy, uint32_t sx,
                        double u1, double u2, float &rox, float &roy, float &roz, float &rdx, float &rdy, float &rdz) {
 #if defined(__HIP_DEVICE_COMPILE__)
     const bool ok = camera_ray_t<true>(c, w, h, i, j, sy, sx, u1, u2, rox, roy, roz, rdx, rdy, rdz);
@@ -595,10 +611,13 @@ APT_HD double unit_from_bits(uint64_t z) {
 // The two uniforms of path p are outputs 2p+1 and 2p+2 of ONE SplitMix64 generator (state += phi; output =
 // mix(state)) whose state starts at splitmix64(seed): every path reads its own two consecutive outputs of the
 // same well-tested stream by random access, state(p) = splitmix64(seed) + 2p*phi.  52 high bits each.
-APT_HD void path_uniforms(uint64_t seed, uint64_t path, double &u1, double &u2) {
-    const uint64_t state = splitmix64(seed) + path * 0x3C6EF372FE94F82Aull; // 2*phi mod 2^64
+constexpr uint64_t kPathStride = 0x3C6EF372FE94F82Aull; // 2*phi mod 2^64: the generator state advances by this per path
+APT_HD void path_uniforms_at(uint64_t state, double &u1, double &u2) {   // state = splitmix64(seed) + path * kPathStride
     u1 = unit_from_bits(splitmix64(state));
     u2 = unit_from_bits(splitmix64(state + 0x9E3779B97F4A7C15ull));
+}
+APT_HD void path_uniforms(uint64_t seed, uint64_t path, double &u1, double &u2) {
+    path_uniforms_at(splitmix64(seed) + path * kPathStride, u1, u2);
 }
 
 // ---- uniform grid over the small spheres of a large scene ----------------------------------------

@@ -58,9 +58,14 @@ struct QueueArgs {
 __host__ __device__ inline uint32_t queue_buf_bytes(uint32_t maxleaf) { return 4u * maxleaf * 12u + 16u; }
 // LDS of render_frame_queue8_kernel (all of it dynamic, so that the ray pool sits at LDS address 0 and a pool entry's address
 // needs no base added), in bytes from its start: pool_a | pool_b | scene table | camera | roulette keys | stack | colours
+// (8576 bytes at S = 64 without roulette.  gfx950 hands out LDS in granules of 1280 bytes -- 128 per CU --, so 7 granules = 18 waves per CU
+// whatever is shaved off down to 7680 bytes: a round-4 layout of 8176 bytes -- 16-bit colour addresses in a third pool array, no stored
+// bounce countdown, compact camera -- measured 16.24 against 16.06 ms at C2 with retirement, its two extra address instructions per
+// refill bought nothing.  Only the compact camera is kept.)
+constexpr uint32_t kQueueTabFloats4 = 16;                // 8 centres + 8 albedos (the grid form keeps its always-tested pair slots there)
 __host__ __device__ inline uint32_t queue_lds_off_tab() { return 2u * kPool * 16u; }
-__host__ __device__ inline uint32_t queue_lds_off_cam() { return queue_lds_off_tab() + (uint32_t)kTab8Floats4 * 16u; }
-__host__ __device__ inline uint32_t queue_lds_off_key() { return queue_lds_off_cam() + (uint32_t)sizeof(Camera); }
+__host__ __device__ inline uint32_t queue_lds_off_cam() { return queue_lds_off_tab() + kQueueTabFloats4 * 16u; }
+__host__ __device__ inline uint32_t queue_lds_off_key() { return queue_lds_off_cam() + (uint32_t)sizeof(CameraLite); }
 __host__ __device__ inline uint32_t queue_lds_off_stack(bool rr, uint32_t nbuf) { (void)nbuf; return queue_lds_off_key() + (rr ? kPool * 8u : 0u); }
 __host__ __device__ inline uint32_t queue_lds_off_colq(bool rr, uint32_t nbuf, bool stack) {
     return queue_lds_off_stack(rr, nbuf) + (stack ? (uint32_t)kMaxStack * 3u * 4u * 4u : 0u);
@@ -86,16 +91,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SC == kScene
                                                                  LeafProg lp, QueueArgs qa) {
     extern __shared__ __align__(16) unsigned char qlds[];
     float4 *tab = reinterpret_cast<float4 *>(qlds + queue_lds_off_tab());
-    Camera &cam = *reinterpret_cast<Camera *>(qlds + queue_lds_off_cam());
+    CameraLite &cam = *reinterpret_cast<CameraLite *>(qlds + queue_lds_off_cam());
     const uint32_t lane = threadIdx.x;
     // No static LDS in this kernel, so the dynamic region starts at LDS address 0 (tests/test_isa_hazards.py checks the kernel
     // descriptor's group_segment_fixed_size); a build that breaks this renders nothing rather than reading the wrong pool entries.
     if ((uint32_t)(uintptr_t)qlds != 0u) { report_status(ta, APT_DEV_LDS_BASE); return; }
     if (SC == kSceneGrid && !grid_queue_usable(ta)) return;            // wave-uniform: render_frame_kernel renders this frame (grid_walk == 2)
-    if (lane < sizeof(Camera) / sizeof(double)) (&cam.pos[0])[lane] = (&fa.cam.pos[0])[lane];
+    if (lane == 0) cam = camera_lite(fa.cam);
     Scene8 sc;
     Tab8 tab8{tab, tab + 8};
-    if (SC == kScene8) tab8 = load_scene8(sph, sc, tab); // ends with a barrier
+    if (SC == kScene8) tab8 = load_scene8<false>(sph, sc, tab); // ends with a barrier
     else { sc.planes = false; __syncthreads(); }
     const KeyConsts kc = make_key_consts(ta.eps);
     const bool fast_ok = eps_allows_rootkey(ta.eps);
@@ -146,10 +151,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SC == kScene
         const bool on = lane < nb;
         const uint32_t i = g_off + (on ? lane : 0u);                    // item within the unit: sub * nl + k
         const uint32_t sub = (i >= nl ? 1u : 0u) + (i >= 2u * nl ? 1u : 0u) + (i >= 3u * nl ? 1u : 0u);
-        const uint32_t k = i - sub * nl;
-        const uint64_t path = ((q0 + g_px) * 4u + sub) * S + g_start + k; // gen_data.py:32-36
+        // path = ((q0 + g_px) * 4 + sub) * S + g_start + k (gen_data.py:32-36) with k = i - sub * nl, i.e. a wave-uniform base plus a
+        // 32-bit per-lane offset: the 64-bit index arithmetic and the generator state of the base run on the scalar unit, a lane adds
+        // offset * stride (one 32 x 64 bit product) -- round 3 formed the 64-bit path index and its 64 x 64 bit product per lane.
+        const uint64_t base = (q0 + g_px) * 4u * (uint64_t)S + g_start;
+        const uint32_t off = i + sub * (S - nl);                        // < 4 * S
+        const uint64_t path = base + off;
         double u1, u2;
-        path_uniforms(fa.seed, path, u1, u2);
+        // (splitmix64(seed) is recomputed here, on the scalar unit, rather than kept in two scalar registers across the hot loop)
+        path_uniforms_at(splitmix64(fa.seed) + base * kPathStride + (uint64_t)off * kPathStride, u1, u2);
         float rox, roy, roz, rdx, rdy, rdz;
         camera_ray(cam, fa.width, fa.height, g_pi, g_pj, sub >> 1, sub & 1u, u1, u2, rox, roy, roz, rdx, rdy, rdz);
         const uint32_t e = (pool_head + pool_level + lane) & (kPool - 1u);
@@ -502,7 +512,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SC == kScene
         // profiles/r04_grid_ablation.jsonl) showed that one pass cost 46 % of the C4 frame, five times its instruction share.  Pairs beyond
         // kBigLds (more than 8 large spheres) keep the scalar loads.  Unused LDS pairs hold NaN spheres: a NaN discriminant is never a hit.
         constexpr uint32_t kBigLds = 4;
-        static_assert(2 * kBigLds <= (uint32_t)kTab8Floats4, "the LDS copy uses the 8-sphere table's region");
+        static_assert(2 * kBigLds <= kQueueTabFloats4, "the LDS copy uses the 8-sphere table's region");
         if (lane < 2u * kBigLds) {
             const float qn = __uint_as_float(0x7fc00000u);
             tab[lane] = lane < 2u * min(h.slot_base, kBigLds) ? slot_geom[lane] : make_float4(qn, qn, qn, qn);

@@ -1045,6 +1045,9 @@ __device__ __forceinline__ uint32_t trace_grid(const float *__restrict__ sph, co
 }
 
 // spheres.bin layout [10][8]: r2, x, y, z, em*3, col*3 (gen_data.py:106-127, rt_helper.h:93-102)
+// ONES: also write entry 16 = (1,1,1), the "albedo" of a path that is no longer alive (two-path form, pt_trace2.h); the sample-queue kernels
+// do not use it and keep their camera there (pt_queue.h: every LDS byte counts towards their occupancy).
+template <bool ONES = true>
 __device__ __forceinline__ Tab8 load_scene8(const float *__restrict__ sph, Scene8 &sc, float4 *tab) {
 #pragma unroll
     for (int k = 0; k < 8; ++k) { // constant offsets from a uniform read-only pointer: scalar loads
@@ -1055,7 +1058,7 @@ __device__ __forceinline__ Tab8 load_scene8(const float *__restrict__ sph, Scene
         tab[k] = make_float4(sph[8 + k], sph[16 + k], sph[24 + k], sph[k]);
         tab[8 + k] = make_float4(sph[56 + k], sph[64 + k], sph[72 + k], 0.0f);
     }
-    if (threadIdx.x == 8) tab[16] = make_float4(1.0f, 1.0f, 1.0f, 0.0f); // "albedo" of a path that is no longer alive (pt_trace2.h)
+    if (ONES && threadIdx.x == 8) tab[16] = make_float4(1.0f, 1.0f, 1.0f, 0.0f); // "albedo" of a path that is no longer alive (pt_trace2.h)
     sc.planes = scene8_shares_planes(sc);
     __syncthreads();
     return Tab8{tab, tab + 8};
