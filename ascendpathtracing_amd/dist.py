@@ -20,6 +20,7 @@ The kernels write straight into these regions (no pack step); the root unpacks w
 """
 import json
 import os
+import time
 
 import torch
 import torch.distributed as dist
@@ -57,7 +58,14 @@ class FrameShard:
         self.pixel_count = sum(c for _, c in self.ranges)          # pixels this rank renders
         self.pixel_begin = self.ranges[0][0]                         # (meaningful as a range only for stripes == 1)
         self.device = device if device is not None else ("cuda" if torch.cuda.is_available() else "cpu")
-        self._bufs, self._lists, self._pending = [], [], None
+        self._bufs, self._lists, self._recv, self._pending = [], [], [], None
+        # Root only: where finish() spent its time, per finished gather -- waiting for the collective (what the render of the next
+        # frame did not cover) and scattering the stripes into the frame.  GPU: event pairs on the unpack stream (read by timings());
+        # CPU: host seconds.
+        self._on_gpu = str(self.device).startswith("cuda")
+        self._side = torch.cuda.Stream(device=self.device) if (self._on_gpu and rank == 0) else None   # the unpack runs beside the next render
+        self._unpacked = {}            # slot -> event: its receive buffer has been read by the unpack
+        self._marks = []               # (wait begin, wait end = unpack begin, unpack end)
 
     # ---- layout ------------------------------------------------------------------------------------
     @property
@@ -82,7 +90,10 @@ class FrameShard:
         """Allocates the packed buffers; -> per slot the list of (fb, u8) views, one pair per stripe."""
         self._bufs = [torch.zeros(self.packed_bytes, dtype=torch.uint8, device=self.device) for _ in range(self.slots)]
         if self.rank == 0:
-            self._lists = [[torch.empty_like(self._bufs[0]) for _ in range(self.world)] for _ in range(self.slots)]
+            # ONE receive tensor per slot, [world][packed_bytes] (the gather's list = its rows): the unpack reads a whole group of ranks
+            # with one strided copy instead of one copy per rank
+            self._recv = [torch.empty((self.world, self.packed_bytes), dtype=torch.uint8, device=self.device) for _ in range(self.slots)]
+            self._lists = [[r[k] for k in range(self.world)] for r in self._recv]
         counts = [c for _, c in self.ranges]
         return [self._views(b, counts) for b in self._bufs]
 
@@ -99,12 +110,33 @@ class FrameShard:
         for (b, c), (fb, u8) in zip(self.ranges, slot_views):
             render_fn(p, spheres, b, c, fb=fb, fb_u8=u8)
 
-    def _unpack(self, bufs, full_fb, full_u8):
-        for r, buf in enumerate(bufs):
-            ranges = stripe_ranges(self.npix, r, self.world, self.stripes)
-            for (b, c), (fb, u8) in zip(ranges, self._views(buf, [c for _, c in ranges])):
-                full_fb[:, b:b + c] = fb
-                full_u8[b:b + c] = u8
+    def _unpack(self, recv, full_fb, full_u8):
+        """recv [ranks][packed_bytes] -> the full frame.  Stripe s of ranks 0 .. world-1 are the consecutive parts s*world ..
+        s*world + world-1 of the frame's world*stripes parts, i.e. ONE contiguous pixel run in which the first parts may be one pixel
+        longer than the rest (split_range): at most two groups of equal-length parts per stripe, each moved by one strided copy for
+        the float planes and one for the bytes (2 * stripes * (1 or 2) copies per frame; before round 4: 2 * stripes * world)."""
+        ranks, ms = recv.shape[0], self.max_stripe
+        parts = self.world * self.stripes
+        base, extra = divmod(self.npix, parts)
+        for s in range(self.stripes):
+            p0 = s * self.world                                   # first part of this stripe's run
+            groups = []
+            if ranks != self.world:                               # a single local buffer (no process group): its own parts only
+                groups = [(self.rank, 1)]
+            else:
+                n_long = max(0, min(self.world, extra - p0))      # parts p0 .. p0 + n_long - 1 have base + 1 pixels
+                if n_long:
+                    groups.append((0, n_long))
+                if n_long < self.world:
+                    groups.append((n_long, self.world - n_long))
+            off = self.stripe_bytes * s
+            for r0, n in groups:
+                b, c = split_range(self.npix, p0 + r0, parts)
+                rows = recv[0:1] if ranks != self.world else recv[r0:r0 + n]
+                fb = rows[:, off:off + 12 * c].view(torch.float32).view(n, 3, c)
+                u8 = rows[:, off + 12 * ms:off + 12 * ms + 3 * c].view(n, c, 3)
+                full_fb[:, b:b + n * c].unflatten(1, (n, c)).copy_(fb.permute(1, 0, 2))
+                full_u8[b:b + n * c].unflatten(0, (n, c)).copy_(u8)
 
     def pixel_counts(self):
         """Pixels every rank of the group renders (all ranks know the whole split)."""
@@ -116,6 +148,7 @@ class FrameShard:
         single rank -- it goes through torch.distributed (RCCL on GPUs).  Blocking form of gather_async."""
         self.gather_async(slot, full_fb, full_u8)
         self.finish()
+        self.drain()
 
     def gather_async(self, slot, full_fb=None, full_u8=None):
         """Enqueue the gather of slot `slot` (asynchronously: the collective runs on the backend's own
@@ -126,26 +159,69 @@ class FrameShard:
             self._pending = ("local", slot, full_fb, full_u8)
             return
         if self.rank == 0:
+            if slot in self._unpacked:       # the slot's receive buffer may still be read by the unpack of two frames ago (side stream)
+                torch.cuda.current_stream().wait_event(self._unpacked.pop(slot))
             work = dist.gather(self._bufs[slot], self._lists[slot], dst=0, async_op=True)
         else:
             work = dist.gather(self._bufs[slot], None, dst=0, async_op=True)
         self._pending = (work, slot, full_fb, full_u8)
 
     def finish(self):
-        """Wait for the pending gather (if any) and, on the root, scatter the stripes into the frame."""
+        """Wait for the pending gather (if any) and, on the root, scatter the stripes into the frame.  On a GPU the wait and the
+        scatter run on a side stream (the next frame's render, already queued on the current stream, is not held up by them); the
+        current stream joins the side stream in drain()."""
         if self._pending is None:
             return
         work, slot, full_fb, full_u8 = self._pending
         self._pending = None
         if work == "local":
-            bufs = [self._bufs[slot]]
-        else:
+            if full_fb is not None:
+                self._unpack(self._bufs[slot].unsqueeze(0), full_fb, full_u8)
+            return
+        if self.rank != 0:
             work.wait()
-            if self.rank != 0:
-                return
-            bufs = self._lists[slot]
-        if full_fb is not None:
-            self._unpack(bufs, full_fb, full_u8)
+            return
+        if self._side is None:                                    # CPU (gloo): host clocks
+            t0 = time.perf_counter()
+            work.wait()
+            t1 = time.perf_counter()
+            if full_fb is not None:
+                self._unpack(self._recv[slot], full_fb, full_u8)
+            self._marks.append((t0, t1, time.perf_counter()))
+            return
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        self._side.wait_stream(torch.cuda.current_stream())       # (the frame tensors were made on the current stream)
+        with torch.cuda.stream(self._side):
+            ev[0].record()
+            work.wait()                                           # the side stream waits for the collective
+            ev[1].record()
+            if full_fb is not None:
+                self._unpack(self._recv[slot], full_fb, full_u8)
+            ev[2].record()
+        self._unpacked[slot] = ev[2]
+        self._marks.append(tuple(ev))
+
+    def drain(self):
+        """The current stream waits for everything finish() put on the side stream (call before reading the full frame)."""
+        if self._side is not None:
+            torch.cuda.current_stream().wait_stream(self._side)
+
+    def timings(self):
+        """Root: mean milliseconds per finished gather spent (a) waiting for the collective after the next render had been queued and
+        (b) scattering the stripes into the frame -> {"gather_wait_ms", "unpack_ms", "gathers"}; call after a device synchronise."""
+        if not self._marks:
+            return {"gather_wait_ms": None, "unpack_ms": None, "gathers": 0}
+        if self._side is None:
+            wait = [1e3 * (b - a) for a, b, _ in self._marks]
+            unp = [1e3 * (c - b) for _, b, c in self._marks]
+        else:
+            wait = [a.elapsed_time(b) for a, b, _ in self._marks]
+            unp = [b.elapsed_time(c) for _, b, c in self._marks]
+        n = len(self._marks)
+        return {"gather_wait_ms": round(sum(wait) / n, 4), "unpack_ms": round(sum(unp) / n, 4), "gathers": n}
+
+    def reset_timings(self):
+        self._marks = []
 
 
 def render_frame_sharded(params: RenderParams, spheres, rank=None, world=None, render_fn=None, device=None, stripes=1):
@@ -165,6 +241,7 @@ def render_frame_sharded(params: RenderParams, spheres, rank=None, world=None, r
     shard.render(views, spheres, render_fn)
     full = shard.alloc_full() if rank == 0 else (None, None)
     shard.gather(0, *full)
+    shard.drain()
     return full
 
 

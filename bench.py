@@ -266,6 +266,7 @@ def dry_run(args):
         if world > 1:
             shard.gather_async(k % 2, *full)
     shard.finish()
+    shard.drain()
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
@@ -280,7 +281,9 @@ def dry_run(args):
         print(json.dumps({"metric": "dry run (no render, no measurement)", "dry_run": True, "value": None, "unit": "Mray/s", "n_gpus": world,
                           "steps": args.steps, "warmup": args.warmup, "scaling": "strong" if world > 1 else "weak",
                           "config": {"workload": f"{cfg['name']} geometry at toy size {W}x{H}", "pixels_per_rank": shard.pixel_count,
-                                     "stripes": shard.stripes}, "gathered_frame_complete": ok}), flush=True)
+                                     "stripes": shard.stripes, "collective": "gloo gather (rehearsal)", "peer_access": None},
+                          "ranks": ({"gather": shard.timings()} if world > 1 else None),
+                          "gathered_frame_complete": ok}), flush=True)
     if world > 1:
         dist.destroy_process_group()
 
@@ -377,6 +380,7 @@ def main():
 
     def sync():
         shard.finish()
+        shard.drain()                         # the root's unpack runs on a side stream
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -384,6 +388,7 @@ def main():
     for k in range(args.warmup):
         step(k)
     sync()
+    shard.reset_timings()                     # the gather / unpack split below covers the timed steps only
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     t0 = time.perf_counter()
     for k, e in enumerate(ev):
@@ -441,6 +446,15 @@ def main():
                      "traffic": traffic, "traffic_recorded_for_build": traffic_tag, "build_id": build_id},
         "target_mray_per_gpu": 100.0,
     }
+    if world > 1:       # what the first hardware run needs in order to explain itself: the collective's library, who can reach whom
+        try:
+            nccl = ".".join(str(x) for x in torch.cuda.nccl.version())
+        except Exception:                     # noqa: BLE001
+            nccl = None
+        peers = [[bool(i == j or torch.cuda.can_device_access_peer(i, j)) for j in range(ndev)] for i in range(ndev)]
+        out["config"].update({"collective": f"torch.distributed gather, backend {dist.get_backend()} (RCCL), NCCL API version {nccl}",
+                              "visible_devices": ndev, "peer_access": peers,
+                              "hsa_enable_ipc_mode_legacy": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")})
     if world > 1:       # strong scaling: the frame takes max(band kernel) + whatever the gather / sync leaves uncovered
         seg_r = [n * 4 * S * D for n in shard.pixel_counts()]            # every rank knows the whole split
         out["ranks"] = {"kernel_ms_per_rank": [round(x, 3) for x in per_rank_ms],
@@ -449,6 +463,10 @@ def main():
                                               for r in range(world)],
                         "slowest_band_kernel_ms": round(max(per_rank_ms), 3),
                         "uncovered_gather_and_sync_ms_per_step": round(ms_per_step - max(per_rank_ms), 3),
+                        # the root's side of it, per gather (events on the unpack stream): the wait for the collective that the next
+                        # frame's render did not cover, and the scatter of the stripes into the frame (one strided copy per group of ranks)
+                        "gather": shard.timings(),
+                        "gather_bytes_per_rank": shard.packed_bytes,
                         "load_imbalance_max_over_mean": round(max(per_rank_ms) / (sum(per_rank_ms) / world), 4)}
     if rank == 0 and world > 1 and workload == "c3":
         out["quality"] = gathered_frame_check(*full)       # the last frame's gather has finished (sync above)

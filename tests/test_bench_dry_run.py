@@ -31,6 +31,10 @@ def test_torchrun_bench_dry_run(n, extra):
     assert out["dry_run"] is True and out["n_gpus"] == n and out["steps"] == 3 and out["warmup"] == 1
     assert out["scaling"] == "strong" and out["gathered_frame_complete"] is True
     assert "C3" in out["config"]["workload"]
+    # the N > 1 line splits what the gather leaves uncovered into the wait for the collective and the unpack
+    g = out["ranks"]["gather"]
+    assert g["gathers"] == 3 + 1 and g["gather_wait_ms"] >= 0 and g["unpack_ms"] >= 0
+    assert "collective" in out["config"] and "peer_access" in out["config"]
 
 
 def test_single_process_dry_run_and_world_mismatch():
