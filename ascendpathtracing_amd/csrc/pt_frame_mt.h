@@ -166,4 +166,176 @@ __global__ __launch_bounds__(kBlock, APT_TWO_WAVES) void render_frame_mt_kernel(
     count_traced(ta, traced);
 }
 
+// ---- the same pipeline for EVERY sample count (round 4) ---------------------------------------------------------------------------
+// 78 pixels are 312 S paths = 2 S generator blocks for ANY S, so the group structure above needs no power of two; what does is the
+// summation stage (runs of S samples that tile a 512-path round).  This kernel keeps the colours of the last TWO rounds in a 1024-entry
+// LDS ring and, after every round, sums the pairwise LEAVES (pt_leaf.h: numpy's np.mean plan of a run of S samples -- S < 8: a plain
+// loop; leaves of <= 128 samples with 8 interleaved accumulators and an in-order n % 8 tail; halves combined through a stack) that END in
+// that round: a leaf is at most 128 samples long, so all of it is still in the ring.  One 8-lane task per (run, channel); the partial-sum
+// stack of the one run that is still open at the end of a round carries over to the next.  S = 1 (the reference's own default,
+// src/common.h:4-6), 2, 4, non-powers of two and counts above 256 run through this kernel; {8, ..., 256} keep the kernel above (its sums
+// are a fixed 24 lanes per run: C2 22.6 ms).  Same arithmetic, operation for operation, as gen_rays_mt -> render_do_ex -> decode_color.
+constexpr uint32_t kMtColRing = 2 * kMtRound;  // colours kept: this round's and the previous one's
+constexpr uint32_t kMtOpenSlots = 8;           // runs that can be open or touched in one round when a run has several leaves (S > 128: <= 5)
+
+template <int MODE>
+__global__ __launch_bounds__(kBlock, APT_TWO_WAVES) void render_frame_mt_any_kernel(const float *__restrict__ sph, FrameArgs fa, TraceArgs ta, MtFrameArgs ma,
+                                                                                    LeafProg lp) {
+    __shared__ float4 tab[kTab8Floats4];
+    __shared__ Camera cam;
+    __shared__ __align__(16) uint32_t ring[kMtRing];          // y[n] at ring[n % 4096]
+    __shared__ float cring[3 * kMtColRing];                    // [channel][path index mod 1024]
+    __shared__ float submean[kMtGroupPixels * 4 * 3];          // [pixel of the group][sub-pixel][channel]
+    __shared__ float stk[kMtOpenSlots * 3 * kMaxStack];        // pairwise stacks of the runs touched in a round (nleaves > 1 only)
+    const uint32_t t = threadIdx.x;
+    if (t < sizeof(Camera) / sizeof(double)) (&cam.pos[0])[t] = (&fa.cam.pos[0])[t];
+    Scene8 sc;
+    const Tab8 tab8 = load_scene8(sph, sc, tab);                // ends with a barrier
+    const bool planes = sc.planes;
+    const Gain3 gain = load_gain(sph, ta);
+    const uint32_t S = fa.samples, H = fa.height, nleaves = lp.nleaves;
+    const uint64_t group = ma.first_group + blockIdx.x;
+    const uint32_t npaths = 312u * S;                           // of this group
+    const uint64_t q0 = group * kMtGroupPixels;                 // first pixel
+    const uint32_t i0 = (uint32_t)(q0 / H), j0 = (uint32_t)(q0 % H);
+    const uint64_t pix_end = fa.pixel_begin + fa.pixel_count;
+    for (uint32_t i = t; i < 624; i += kBlock) ring[i] = ma.checkpoints[(uint64_t)blockIdx.x * 624 + i];   // y[0 .. 623] = the state of the group's first block
+    __syncthreads();
+
+    uint32_t have = 624;                                        // words y[0 .. have) exist
+    uint32_t traced = 0;
+    uint32_t done_run = 0, done_leaf = 0;                       // the first leaf not summed yet: leaf `done_leaf` of run `done_run` (uniform)
+    const uint32_t nrounds = (npaths + kMtRound - 1) / kMtRound;
+    for (uint32_t r = 0; r < nrounds; ++r) {
+        const uint32_t need = min(4u * npaths, 2048u * (r + 1u));
+        while (have < need) {                                   // (the generator: as in render_frame_mt_kernel)
+            if (t < kMtStep) {
+                const uint32_t nn = have - 624u + t;
+                auto twist = [](uint32_t hi, uint32_t lo) { const uint32_t y = (hi & 0x80000000u) | (lo & 0x7fffffffu); return (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u); };
+                const uint32_t a0 = ring[nn & (kMtRing - 1u)], a1 = ring[(nn + 1u) & (kMtRing - 1u)], am = ring[(nn + 397u) & (kMtRing - 1u)];
+                const uint32_t b0 = ring[(nn + 227u) & (kMtRing - 1u)], b1 = ring[(nn + 228u) & (kMtRing - 1u)];
+                const uint32_t w1 = am ^ twist(a0, a1), w2 = w1 ^ twist(b0, b1);
+                ring[(nn + 624u) & (kMtRing - 1u)] = w1;
+                ring[(nn + 851u) & (kMtRing - 1u)] = w2;
+                if (t < kMtThird) {
+                    const uint32_t c0 = ring[(nn + 454u) & (kMtRing - 1u)], c1 = ring[(nn + 455u) & (kMtRing - 1u)];
+                    ring[(nn + 1078u) & (kMtRing - 1u)] = w2 ^ twist(c0, c1);
+                }
+            }
+            have += 2u * kMtStep + kMtThird;
+            __syncthreads();
+        }
+        // ---- two paths per thread: local indices l and l + 256 ----
+        PathPair pp;
+        bool valid[2];
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const uint32_t l = r * kMtRound + (uint32_t)half * 256u + t;
+            const uint32_t lc = l < npaths ? l : 0u;            // past the group's end: a harmless stand-in
+            const uint4 w4 = *reinterpret_cast<const uint4 *>(&ring[(4u * lc) & (kMtRing - 1u)]);
+            const uint32_t a1 = mt_temper_word(w4.x) >> 5, b1 = mt_temper_word(w4.y) >> 6, a2 = mt_temper_word(w4.z) >> 5, b2 = mt_temper_word(w4.w) >> 6;
+            const double u1 = ((double)a1 * 67108864.0 + (double)b1) / 9007199254740992.0; // random_sample
+            const double u2 = ((double)a2 * 67108864.0 + (double)b2) / 9007199254740992.0;
+            const uint32_t run = lc / S;                        // sub-pixel run of the group: pixel * 4 + sub  (gen_data.py:32-36)
+            const uint32_t sub = run & 3u, pl = run >> 2;
+            uint32_t jj = j0 + pl, ii = i0;
+            while (jj >= H) { jj -= H; ++ii; }
+            const uint64_t q = q0 + pl;
+            valid[half] = l < npaths && q >= fa.pixel_begin && q < pix_end;
+            float rox, roy, roz, rdx, rdy, rdz;
+            camera_ray(cam, fa.width, fa.height, ii, jj, sub >> 1, sub & 1u, u1, u2, rox, roy, roz, rdx, rdy, rdz);
+            if (half == 0) { pp.ox.x = rox; pp.oy.x = roy; pp.oz.x = roz; pp.dx.x = rdx; pp.dy.x = rdy; pp.dz.x = rdz; }
+            else { pp.ox.y = rox; pp.oy.y = roy; pp.oz.y = roz; pp.dx.y = rdx; pp.dy.y = rdy; pp.dz.y = rdz; }
+        }
+        pp.rx = pp.ry = pp.rz = f2{1.0f, 1.0f};
+        trace2_ns8<MODE>(sc, tab8, pp, ta, planes);
+        traced += (valid[0] ? ta.depth : 0u) + (valid[1] ? ta.depth : 0u);
+        {
+            const uint32_t la = (r * kMtRound + t) & (kMtColRing - 1u), lb = (r * kMtRound + 256u + t) & (kMtColRing - 1u);
+            cring[la] = pp.rx.x * gain.r; cring[kMtColRing + la] = pp.ry.x * gain.g; cring[2 * kMtColRing + la] = pp.rz.x * gain.b; // render.cpp:194-196
+            cring[lb] = pp.rx.y * gain.r; cring[kMtColRing + lb] = pp.ry.y * gain.g; cring[2 * kMtColRing + lb] = pp.rz.y * gain.b;
+        }
+        __syncthreads();
+        // ---- np.mean of every run (data_visualization.py:41-45): the leaves that are complete now, run by run ----
+        const uint32_t avail = min(npaths, kMtRound * (r + 1u));   // paths [0, avail) have their colour
+        // runs touched: from the open run to the last run with a complete leaf; every task walks its run's leaves in plan order
+        const uint32_t first_run = done_run;
+        const uint32_t last_run = min(312u - 1u, (avail - 1u) / S);        // the run holding the last available path
+        const uint32_t nrun_tasks = last_run - first_run + 1u, lanes_needed = nrun_tasks * 24u;
+        for (uint32_t base = 0; base < lanes_needed; base += kBlock) {
+            const uint32_t tid = base + t;
+            const bool on = tid < lanes_needed;
+            const uint32_t task = on ? tid >> 3 : 0u, j = tid & 7u;
+            const uint32_t slot = task / 3u, ch = task - slot * 3u;
+            const uint32_t run = first_run + slot, rbase = run * S;
+            const float *col = cring + ch * kMtColRing;
+            float *st = stk + ((slot & (kMtOpenSlots - 1u)) * 3u + ch) * kMaxStack;
+            uint32_t start = 0, sp = 0;
+            for (uint32_t i = 0; i < nleaves; ++i) {
+                const uint32_t n = lp.len(i);
+                const bool mine = (run > done_run || i >= done_leaf) && rbase + start + n <= avail;   // not summed yet, and complete
+                if (run == done_run && i < done_leaf) { sp += 1u - lp.ncomb(i); start += n; continue; }   // summed in an earlier round (uniform per task)
+                if (!mine) break;                               // this leaf (and all later ones) ends in a later round
+                // numpy pairwise_sum of a[0 .. n): n < 8 a plain loop from 0; else 8 accumulators, tree, tail in order
+                const uint32_t a0 = rbase + start;
+                float acc;
+                if (n < 8u) {
+                    acc = 0.0f;
+                    for (uint32_t k = 0; k < n; ++k) acc = acc + col[(a0 + k) & (kMtColRing - 1u)];
+                } else {
+                    const uint32_t nfull = n & ~7u;
+                    acc = col[(a0 + j) & (kMtColRing - 1u)];
+                    for (uint32_t i8 = 8; i8 < nfull; i8 += 8) acc = acc + col[(a0 + i8 + j) & (kMtColRing - 1u)];
+                    acc = acc + __shfl_xor(acc, 1, 64);         // ((r0+r1)+(r2+r3)) + ((r4+r5)+(r6+r7))
+                    acc = acc + __shfl_xor(acc, 2, 64);
+                    acc = acc + __shfl_xor(acc, 4, 64);
+                    for (uint32_t k = nfull; k < n; ++k) acc = acc + col[(a0 + k) & (kMtColRing - 1u)];   // res += a[i], in order (every lane the same)
+                }
+                if (nleaves == 1u) {
+                    if (on && j == 0) submean[run * 3u + ch] = acc / (float)S;   // np.mean: float32 sum / count
+                } else {                                        // pairwise(left) + pairwise(right), innermost first (the 8 lanes hold equal values)
+                    float top = acc;
+                    uint32_t sp1 = sp + 1u;
+                    for (uint32_t m = 0; m < lp.ncomb(i); ++m) { --sp1; top = st[sp1 - 1u] + top; }
+                    if (on && j == 0) st[sp1 - 1u] = top;
+                    if (i + 1u == nleaves && on && j == 0) submean[run * 3u + ch] = top / (float)S;
+                }
+                sp += 1u - lp.ncomb(i);
+                start += n;
+            }
+        }
+        __syncthreads();
+        {   // advance the cursor (uniform): leaves complete up to `avail`
+            uint32_t run = done_run, leaf = done_leaf, start = 0;
+            for (uint32_t i = 0; i < leaf; ++i) start += lp.len(i);
+            while (run < 312u && run * S + start + lp.len(leaf) <= avail) {
+                start += lp.len(leaf);
+                if (++leaf == nleaves) { leaf = 0; start = 0; ++run; }
+            }
+            // the open run becomes slot 0 of the next round: move its stack there
+            if (nleaves > 1u && run < 312u && run != first_run && t < 3u * kMaxStack) {
+                const uint32_t from = (run - first_run) & (kMtOpenSlots - 1u);
+                stk[t] = stk[from * 3u * kMaxStack + t];
+            }
+            done_run = run; done_leaf = leaf;
+        }
+        __syncthreads();
+    }
+    // ---- decode_color (data_visualization.py:36-57): four sub-pixel means in float64, / 4, clip, 8-bit by truncation ----
+    for (uint32_t k = t; k < kMtGroupPixels * 3u; k += kBlock) {
+        const uint32_t pl = k / 3u, ch = k - pl * 3u;
+        const uint64_t q = q0 + pl;
+        if (q < fa.pixel_begin || q >= pix_end) continue;
+        double acc = 0.0;
+#pragma unroll
+        for (int sq = 0; sq < 4; ++sq) acc = acc + (double)submean[(pl * 4u + (uint32_t)sq) * 3u + ch];
+        const double v = acc / 4;
+        const double cl = v < 0 ? 0 : (v > 1 ? 1 : v);
+        const uint64_t o = q - fa.pixel_begin;
+        fa.fb[(uint64_t)ch * fa.pixel_count + o] = (float)cl;
+        if (fa.fb_u8) fa.fb_u8[o * 3 + ch] = (uint8_t)(cl * 255);
+    }
+    count_traced(ta, traced);
+}
+
 } // namespace

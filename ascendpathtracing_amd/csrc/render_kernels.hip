@@ -764,8 +764,11 @@ int apt_render_frame_mt(const apt_render_params *p, void *stream, const uint32_t
     if (p->flags & APT_FLAG_RR) return fail(APT_ERR_ARG, "apt_render_frame_mt: APT_FLAG_RR is not part of the reference's pipeline%s");
     uint32_t log2_s = 0;
     while ((1u << log2_s) < p->samples) ++log2_s;
-    if ((1u << log2_s) != p->samples || p->samples < 8 || p->samples > 256)
-        return fail(APT_ERR_ARG, "apt_render_frame_mt: samples must be 8, 16, 32, 64, 128 or 256 (other counts: the banded three-kernel pipeline)%s");
+    // 78 pixels are 2 * samples generator blocks for every sample count; samples in {8, 16, ..., 256} take the kernel whose sums are a
+    // fixed 24 lanes per run, every other count (1, 2, 4 -- the reference's default is 1 --, non-powers of two, > 256) the general one
+    const bool pow2_kernel = (1u << log2_s) == p->samples && p->samples >= 8 && p->samples <= 256;
+    LeafProg lp;
+    if ((rc = make_leaf_prog(p->samples, lp))) return rc;
     const uint64_t npix = (uint64_t)p->width * p->height;
     if (pixel_begin > npix || pixel_count > npix - pixel_begin) return fail(APT_ERR_ARG, "pixel range beyond the image%s");
     if (pixel_count == 0) return APT_OK;
@@ -780,8 +783,13 @@ int apt_render_frame_mt(const apt_render_params *p, void *stream, const uint32_t
     MtFrameArgs ma;
     ma.checkpoints = checkpoints + (g_lo - first_group) * 624; ma.first_group = g_lo; ma.log2_s = log2_s;
     const dim3 grid((unsigned)(g_hi - g_lo));
-    if (p->mode == APT_MODE_ORACLE) hipLaunchKernelGGL((render_frame_mt_kernel<kModeOracle>), grid, dim3(kBlock), 0, (hipStream_t)stream, spheres, fa, ta, ma);
-    else hipLaunchKernelGGL((render_frame_mt_kernel<kModeKernel>), grid, dim3(kBlock), 0, (hipStream_t)stream, spheres, fa, ta, ma);
+    if (pow2_kernel) {
+        if (p->mode == APT_MODE_ORACLE) hipLaunchKernelGGL((render_frame_mt_kernel<kModeOracle>), grid, dim3(kBlock), 0, (hipStream_t)stream, spheres, fa, ta, ma);
+        else hipLaunchKernelGGL((render_frame_mt_kernel<kModeKernel>), grid, dim3(kBlock), 0, (hipStream_t)stream, spheres, fa, ta, ma);
+    } else {
+        if (p->mode == APT_MODE_ORACLE) hipLaunchKernelGGL((render_frame_mt_any_kernel<kModeOracle>), grid, dim3(kBlock), 0, (hipStream_t)stream, spheres, fa, ta, ma, lp);
+        else hipLaunchKernelGGL((render_frame_mt_any_kernel<kModeKernel>), grid, dim3(kBlock), 0, (hipStream_t)stream, spheres, fa, ta, ma, lp);
+    }
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? APT_OK : hip_fail(e);
 }

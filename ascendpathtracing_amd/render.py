@@ -341,8 +341,8 @@ def render_reference_frame_fused(w, h, s, depth=5, seed=0, spheres=None, mode=No
                                  pixel_count=None, checkpoints=None, mt_state=None):
     """The reference's whole pipeline (np.random.seed(seed); gen_rays; test_soa arithmetic; decode_color) in ONE launch, with no
     ray / colour buffers in HBM (apt_render_frame_mt): -> (fb float32 [3][pixel_count], fb_u8 [pixel_count][3]), not synchronised;
-    bit-identical to render_reference_frame().  s in {8, 16, ..., 256}.  checkpoints = (device int32 tensor [groups][624],
-    first_group) from mt_group_checkpoints() to reuse a table."""
+    bit-identical to render_reference_frame().  Any sample count with a pairwise-sum plan (every s <= 7688; the reference's default is
+    16 x 16, s = 1).  checkpoints = (device int32 tensor [groups][624], first_group) from mt_group_checkpoints() to reuse a table."""
     import numpy as np
     from . import gen_data
     from ._lib import APT_MODE_ORACLE, make_params

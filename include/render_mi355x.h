@@ -274,11 +274,12 @@ int apt_gen_rays_mt_device_ex(const apt_render_params *p, void *stream, const ui
  * APT_MODE_ORACLE the arithmetic of gen_data.py:246-429 test_soa) -> decode_color (scripts/data_visualization.py:36-57),
  * without the [6][N] ray buffer and the [3][N] colour buffer: bit-identical to apt_gen_rays_mt_device -> render_do_ex ->
  * apt_decode_color_device.  One workgroup per GROUP of 78 pixels (78 * 4 * samples paths = 2 * samples generator blocks of
- * 156 paths when samples is a power of two): checkpoints[k] = the raw 624-word state of block (first_group + k) * 2 * samples,
+ * 156 paths, for EVERY sample count): checkpoints[k] = the raw 624-word state of block (first_group + k) * 2 * samples,
  * i.e. apt_mt19937_checkpoints_window(state_in, seed, first_group * 2 * samples, groups * 2 * samples, 2 * samples, ...).  Renders
  * pixels [pixel_begin, pixel_begin + pixel_count) into fb [3][pixel_count] (+ fb_u8 [pixel_count][3] or NULL); the table must
- * cover groups pixel_begin / 78 .. (pixel_begin + pixel_count - 1) / 78.  The 8-sphere scene, samples in {8, 16, ..., 256}, no
- * APT_FLAG_RR (other cases: the three-kernel form, whole or banded).  Enqueues on `stream`, allocates nothing. */
+ * cover groups pixel_begin / 78 .. (pixel_begin + pixel_count - 1) / 78.  The 8-sphere scene, no APT_FLAG_RR; any sample count that has a
+ * pairwise-sum plan (every count <= 7688; since round 4 -- before: 8, 16, ..., 256 only -- incl. the reference's own default, 16 x 16 with
+ * samples = 1, src/common.h:4-6).  Enqueues on `stream`, allocates nothing. */
 int apt_render_frame_mt(const apt_render_params *p, void *stream, const uint32_t *checkpoints, uint64_t num_checkpoints,
                         uint64_t first_group, const float *spheres, uint64_t pixel_begin, uint64_t pixel_count,
                         float *fb, uint8_t *fb_u8);
