@@ -784,7 +784,24 @@ APT_HD void russian_roulette(PathState &s, uint64_t key, uint32_t bounce) { // b
     const uint64_t h = splitmix64(key + 0x9E3779B97F4A7C15ull * (uint64_t)(bounce + 1u));
     const float u = (float)((uint32_t)(h >> 32) >> 8) * 0x1p-24f;   // the 24 high bits (written on the high dword: a 32-bit conversion, not a 64-bit one)
     if (u >= p) { s.rxy.x = 0.0f; s.rxy.y = 0.0f; s.rz = 0.0f; }
-    else { const float inv = 1.0f / p; s.rxy.x = s.rxy.x * inv; s.rxy.y = s.rxy.y * inv; s.rz = s.rz * inv; }
+    else {
+#if defined(__HIP_DEVICE_COMPILE__)
+        // 1 / p, correctly rounded, for p in [0.05, 0.95]: hipcc's own expansion of the IEEE divide (refined v_rcp_f32, quotient, two
+        // residual corrections) without its v_div_scale / v_div_fmas / v_div_fixup frame, which is the identity when neither operand
+        // nor quotient comes near the ends of the exponent range (the sequence of div3_shared() with numerator 1, checked bit for bit
+        // against '/' by apt_selftest_div3; the frames with roulette equal the CPU restatement's 1.0f / p bit for bit)
+        const float r0 = __builtin_amdgcn_rcpf(p);
+        const float e0 = __builtin_fmaf(-p, r0, 1.0f);
+        const float r1 = __builtin_fmaf(e0, r0, r0);
+        float e = __builtin_fmaf(-p, r1, 1.0f);
+        float q = __builtin_fmaf(e, r1, r1);
+        e = __builtin_fmaf(-p, q, 1.0f);
+        const float inv = __builtin_fmaf(e, r1, q);
+#else
+        const float inv = 1.0f / p;
+#endif
+        s.rxy.x = s.rxy.x * inv; s.rxy.y = s.rxy.y * inv; s.rz = s.rz * inv;
+    }
 }
 
 #endif // __clang__

@@ -66,7 +66,9 @@ constexpr uint32_t kQueueTabFloats4 = 16;                // 8 centres + 8 albedo
 __host__ __device__ inline uint32_t queue_lds_off_tab() { return 2u * kPool * 16u; }
 __host__ __device__ inline uint32_t queue_lds_off_cam() { return queue_lds_off_tab() + kQueueTabFloats4 * 16u; }
 __host__ __device__ inline uint32_t queue_lds_off_key() { return queue_lds_off_cam() + (uint32_t)sizeof(CameraLite); }
-__host__ __device__ inline uint32_t queue_lds_off_stack(bool rr, uint32_t nbuf) { (void)nbuf; return queue_lds_off_key() + (rr ? kPool * 8u : 0u); }
+// (with roulette: the HIGH words of the keys, 4 bytes per pool entry; the low word takes the place of the bounce countdown in pool_b, which
+// starts at depth - 1 for every ray and is not stored then -- 9072 -> 8816 bytes at S = 64: 7 instead of 8 LDS granules, 18 instead of 16 waves per CU)
+__host__ __device__ inline uint32_t queue_lds_off_stack(bool rr, uint32_t nbuf) { (void)nbuf; return queue_lds_off_key() + (rr ? kPool * 4u : 0u); }
 __host__ __device__ inline uint32_t queue_lds_off_colq(bool rr, uint32_t nbuf, bool stack) {
     return queue_lds_off_stack(rr, nbuf) + (stack ? (uint32_t)kMaxStack * 3u * 4u * 4u : 0u);
 }
@@ -110,7 +112,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SC == kScene
 
     float4 *pool_a = reinterpret_cast<float4 *>(qlds);                 // (ox, oy, dx, dy)
     float4 *pool_b = pool_a + kPool;                                   // (oz, dz, colour address, bounce countdown)
-    uint64_t *pool_key = reinterpret_cast<uint64_t *>(qlds + queue_lds_off_key());       // Russian-roulette key (APT_FLAG_RR only)
+    uint32_t *pool_keyhi = reinterpret_cast<uint32_t *>(qlds + queue_lds_off_key());     // Russian-roulette key, high word (APT_FLAG_RR only; low word: pool_b[.].w)
     float *stack = reinterpret_cast<float *>(qlds + queue_lds_off_stack(rr, nbuf));      // [kMaxStack][3][4] when nleaves > 1
     const uint32_t colq_off = queue_lds_off_colq(rr, nbuf, nleaves > 1);
     unsigned char *colq = qlds + colq_off;                              // [nbuf][items][3] floats
@@ -165,8 +167,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SC == kScene
         const uint32_t e = (pool_head + pool_level + lane) & (kPool - 1u);
         if (on) {
             pool_a[e] = make_float4(rox, roy, rdx, rdy);
-            pool_b[e] = make_float4(roz, rdz, __uint_as_float(qlds_base + colq_off + g_buf * qa.buf_bytes + i * 12u + sub * 4u), __uint_as_float(ta.depth - 1u));
-            if (rr) pool_key[e] = rr_path_key(ta.seed, path);
+            const uint32_t ca = qlds_base + colq_off + g_buf * qa.buf_bytes + i * 12u + sub * 4u;
+            if (rr) {
+                const uint64_t k64 = rr_path_key(ta.seed, path);
+                pool_b[e] = make_float4(roz, rdz, __uint_as_float(ca), __uint_as_float((uint32_t)k64));
+                pool_keyhi[e] = (uint32_t)(k64 >> 32);
+            } else {
+                pool_b[e] = make_float4(roz, rdz, __uint_as_float(ca), __uint_as_float(ta.depth - 1u));
+            }
         }
         pool_level += nb;
         g_off += nb;
@@ -293,23 +301,46 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SC == kScene
             asm("v_lshl_add_u32 %0, %1, 4, %2" : "=v"(ea) : "v"(rank), "s"(pool_head << 4));
             ea &= (kPool - 1u) << 4;
             uint64_t saved;
-            asm volatile("s_and_saveexec_b64 %[sv], %[m]\n\t"
-                         "ds_read_b64 %[oxy], %[ea]\n\t"
-                         "ds_read_b64 %[dxy], %[ea] offset:8\n\t"
-                         "ds_read_b32 %[oz], %[ea] offset:%[ob0]\n\t"
-                         "ds_read_b32 %[dz], %[ea] offset:%[ob1]\n\t"
-                         "ds_read_b32 %[ca], %[ea] offset:%[ob2]\n\t"
-                         "ds_read_b32 %[lf], %[ea] offset:%[ob3]\n\t"
-                         "v_pk_add_f32 %[rxy], 1.0, 0 op_sel_hi:[0,0]\n\t"
-                         "v_mov_b32 %[rz], 1.0\n\t"
-                         "s_waitcnt lgkmcnt(0)\n\t"
-                         "s_mov_b64 exec, %[sv]"
-                         : [sv] "=&s"(saved), [oxy] "+v"(st.oxy), [dxy] "+v"(st.dxy), [oz] "+v"(st.oz), [dz] "+v"(st.dz), [ca] "+v"(caddr),
-                           [lf] "+v"(left), [rxy] "+v"(thr_xy), [rz] "+v"(thr_z)
-                         : [m] "s"(take), [ea] "v"(ea), [ob0] "n"(kPool * 16u), [ob1] "n"(kPool * 16u + 4u), [ob2] "n"(kPool * 16u + 8u), [ob3] "n"(kPool * 16u + 12u)
-                         : "scc", "memory");
-            if (rr) {
-                if (select_const(take, 1) != 0) key = pool_key[ea >> 4];
+            if (!rr) {
+                asm volatile("s_and_saveexec_b64 %[sv], %[m]\n\t"
+                             "ds_read_b64 %[oxy], %[ea]\n\t"
+                             "ds_read_b64 %[dxy], %[ea] offset:8\n\t"
+                             "ds_read_b32 %[oz], %[ea] offset:%[ob0]\n\t"
+                             "ds_read_b32 %[dz], %[ea] offset:%[ob1]\n\t"
+                             "ds_read_b32 %[ca], %[ea] offset:%[ob2]\n\t"
+                             "ds_read_b32 %[lf], %[ea] offset:%[ob3]\n\t"
+                             "v_pk_add_f32 %[rxy], 1.0, 0 op_sel_hi:[0,0]\n\t"
+                             "v_mov_b32 %[rz], 1.0\n\t"
+                             "s_waitcnt lgkmcnt(0)\n\t"
+                             "s_mov_b64 exec, %[sv]"
+                             : [sv] "=&s"(saved), [oxy] "+v"(st.oxy), [dxy] "+v"(st.dxy), [oz] "+v"(st.oz), [dz] "+v"(st.dz), [ca] "+v"(caddr),
+                               [lf] "+v"(left), [rxy] "+v"(thr_xy), [rz] "+v"(thr_z)
+                             : [m] "s"(take), [ea] "v"(ea), [ob0] "n"(kPool * 16u), [ob1] "n"(kPool * 16u + 4u), [ob2] "n"(kPool * 16u + 8u), [ob3] "n"(kPool * 16u + 12u)
+                             : "scc", "memory");
+            } else {
+                // with roulette: the entry's fourth word is the key's low half, its high half comes from pool_keyhi (4-byte entries: address
+                // ea / 4), the countdown starts at depth - 1 (wave-uniform)
+                uint32_t klo = (uint32_t)key, khi = (uint32_t)(key >> 32);
+                const uint32_t eh = ea >> 2;
+                asm volatile("s_and_saveexec_b64 %[sv], %[m]\n\t"
+                             "ds_read_b64 %[oxy], %[ea]\n\t"
+                             "ds_read_b64 %[dxy], %[ea] offset:8\n\t"
+                             "ds_read_b32 %[oz], %[ea] offset:%[ob0]\n\t"
+                             "ds_read_b32 %[dz], %[ea] offset:%[ob1]\n\t"
+                             "ds_read_b32 %[ca], %[ea] offset:%[ob2]\n\t"
+                             "ds_read_b32 %[kl], %[ea] offset:%[ob3]\n\t"
+                             "ds_read_b32 %[kh], %[eh] offset:%[okh]\n\t"
+                             "v_mov_b32 %[lf], %[l0]\n\t"
+                             "v_pk_add_f32 %[rxy], 1.0, 0 op_sel_hi:[0,0]\n\t"
+                             "v_mov_b32 %[rz], 1.0\n\t"
+                             "s_waitcnt lgkmcnt(0)\n\t"
+                             "s_mov_b64 exec, %[sv]"
+                             : [sv] "=&s"(saved), [oxy] "+v"(st.oxy), [dxy] "+v"(st.dxy), [oz] "+v"(st.oz), [dz] "+v"(st.dz), [ca] "+v"(caddr),
+                               [lf] "+v"(left), [rxy] "+v"(thr_xy), [rz] "+v"(thr_z), [kl] "+v"(klo), [kh] "+v"(khi)
+                             : [m] "s"(take), [ea] "v"(ea), [eh] "v"(eh), [l0] "s"(ta.depth - 1u), [ob0] "n"(kPool * 16u), [ob1] "n"(kPool * 16u + 4u),
+                               [ob2] "n"(kPool * 16u + 8u), [ob3] "n"(kPool * 16u + 12u), [okh] "n"(2u * kPool * 16u + kQueueTabFloats4 * 16u + (uint32_t)sizeof(CameraLite))
+                             : "scc", "memory");
+                key = ((uint64_t)khi << 32) | klo;
             }
             const uint32_t nt = min((uint32_t)__popcll(want), pool_level);
             pool_head = (pool_head + nt) & (kPool - 1u);
@@ -517,6 +548,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SC == kScene
             const float qn = __uint_as_float(0x7fc00000u);
             tab[lane] = lane < 2u * min(h.slot_base, kBigLds) ? slot_geom[lane] : make_float4(qn, qn, qn, qn);
         }
+        // What the DDA set-up reads of the header -- box corner, cell sizes and counts -- lives in LDS as well (four float4 behind the pair
+        // slots): the per-segment block fetches them with uniform-address reads instead of holding fifteen more scalar registers across the
+        // walk (this kernel's scalar registers are oversubscribed; which ones the allocator spills decided between 45 and 53 ms at C4 / 64 spp
+        // for the same source, round 4).
+        float4 *hl = tab + 2 * kBigLds;
+        static_assert(2 * kBigLds + 4 <= kQueueTabFloats4, "header block behind the always-tested pair slots");
+        if (lane == 0) {
+            hl[0] = make_float4(h.gmin[0], h.gmin[1], h.gmin[2], h.margin);
+            hl[1] = make_float4(h.inv_cell[0], h.inv_cell[1], h.inv_cell[2], __uint_as_float(h.n[0]));
+            hl[2] = make_float4(h.cell[0], h.cell[1], h.cell[2], __uint_as_float(h.n[1]));
+            hl[3] = make_float4(h.gmax[0], h.gmax[1], h.gmax[2], __uint_as_float(h.n[2]));
+        }
+        const uint32_t nbig = h.slot_base;                      // pair slots of the always-tested list
+        const float walk_margin = h.margin;
         __syncthreads();
         // root keys (pt_trace.h KeyConsts), wave-uniform here: scalar registers
         const uint32_t kbias = f32_bits(ta.eps) + 1u, kinit = f32_bits(kMissT) - kbias;
@@ -623,7 +668,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SC == kScene
                     }
                     rem -= s0 ? 1u : (s1 ? 1u << 10 : 1u << 20);
                     // nothing nearer can lie ahead, or the next cell is outside the grid (an axis with no steps left lost its guard bit)
-                    stop = tmin < te - (1e-3f * fabsf(te) + h.margin) || (rem & kGuard) != kGuard;
+                    stop = tmin < te - (1e-3f * fabsf(te) + walk_margin) || (rem & kGuard) != kGuard;
                     if (!stop) fetch_range();
                 }
             }
@@ -764,12 +809,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SC == kScene
                         for (uint32_t j = 0; j < 2u * kBigLds; ++j) big[j] = tab[j];
 #pragma unroll
                         for (uint32_t j = 0; j < kBigLds; ++j) {
-                            if (j < h.slot_base) {                  // wave-uniform
+                            if (j < nbig) {                         // wave-uniform
                                 test_pair(big[2 * j], big[2 * j + 1], 2 * j, std::false_type{});
                                 if (STATS) n_tests += 2;
                             }
                         }
-                        for (uint32_t j = kBigLds; j < h.slot_base; ++j) {
+                        for (uint32_t j = kBigLds; j < nbig; ++j) {
                             f32x8 g8;
                             asm volatile("s_load_dwordx8 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(g8) : "s"(slot_geom + 2 * j) : "memory");
                             test_pair(make_float4(g8[0], g8[1], g8[2], g8[3]), make_float4(g8[4], g8[5], g8[6], g8[7]), 2 * j, std::false_type{});
@@ -784,14 +829,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SC == kScene
                     // when some starting lane's origin lies outside (wave-level, rare) does the slab test decide where -- whether -- its ray
                     // enters the box (round 3 ran slab test, entry point and clamps for every segment: ~55 of this block's vector instructions).
                     const float ix = __builtin_amdgcn_rcpf(s.dxy.x), iy = __builtin_amdgcn_rcpf(s.dxy.y), iz = __builtin_amdgcn_rcpf(s.dz);
-                    const int n0 = (int)h.n[0], n1 = (int)h.n[1], n2 = (int)h.n[2];
-                    const float e0 = s.oxy.x - h.gmin[0], e1 = s.oxy.y - h.gmin[1], e2 = s.oz - h.gmin[2];   // origin relative to the box corner
+                    const float4 hg = hl[0], hi4 = hl[1], hc = hl[2], hx = hl[3];   // (gmin, margin) (1 / cell, n0) (cell, n1) (gmax, n2): LDS broadcasts
+                    const int n0 = (int)__float_as_uint(hi4.w), n1 = (int)__float_as_uint(hc.w), n2 = (int)__float_as_uint(hx.w);
+                    const float e0 = s.oxy.x - hg.x, e1 = s.oxy.y - hg.y, e2 = s.oz - hg.z;   // origin relative to the box corner
                     auto cell_of = [](float f) __attribute__((always_inline)) -> int {   // floor + convert in one instruction (saturating; NaN -> 0)
                         int c;
                         asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(c) : "v"(f));
                         return c;
                     };
-                    int c0 = cell_of(e0 * h.inv_cell[0]), c1 = cell_of(e1 * h.inv_cell[1]), c2 = cell_of(e2 * h.inv_cell[2]);
+                    int c0 = cell_of(e0 * hi4.x), c1 = cell_of(e1 * hi4.y), c2 = cell_of(e2 * hi4.z);
                     const bool inside = (uint32_t)c0 < (uint32_t)n0 && (uint32_t)c1 < (uint32_t)n1 && (uint32_t)c2 < (uint32_t)n2;
                     bool go = true;
                     float tn = 0.0f;
@@ -806,17 +852,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SC == kScene
                                 tf = fminf(tf, fmaxf(t1, t2));
                             } else if (!(o >= lo && o <= hi)) inbox = false;
                         };
-                        slab(s.oxy.x, s.dxy.x, ix, h.gmin[0], h.gmax[0]);
-                        slab(s.oxy.y, s.dxy.y, iy, h.gmin[1], h.gmax[1]);
-                        slab(s.oz, s.dz, iz, h.gmin[2], h.gmax[2]);
+                        slab(s.oxy.x, s.dxy.x, ix, hg.x, hx.x);
+                        slab(s.oxy.y, s.dxy.y, iy, hg.y, hx.y);
+                        slab(s.oz, s.dz, iz, hg.z, hx.z);
                         go = inbox && tn <= tf;
                         auto entry_cell = [&](float e, float dv, float invw, int na) __attribute__((always_inline)) -> int {
                             const int ci = (int)floorf((e + dv * tn) * invw);      // (an origin inside has tn = 0: the cell computed above)
                             return ci < 0 ? 0 : (ci >= na ? na - 1 : ci);
                         };
-                        c0 = entry_cell(e0, s.dxy.x, h.inv_cell[0], n0);
-                        c1 = entry_cell(e1, s.dxy.y, h.inv_cell[1], n1);
-                        c2 = entry_cell(e2, s.dz, h.inv_cell[2], n2);
+                        c0 = entry_cell(e0, s.dxy.x, hi4.x, n0);
+                        c1 = entry_cell(e1, s.dxy.y, hi4.y, n1);
+                        c2 = entry_cell(e2, s.dz, hi4.z, n2);
                     }
                     if (go) {
                         // per axis: the parameter of the boundary ahead -- plane ci + 1 (dv > 0) or ci (dv < 0) of the axis, relative to the
@@ -833,9 +879,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SC == kScene
                             steps = (uint32_t)(fwd ? na - 1 - ci : ci);
                         };
                         uint32_t l0, l1, l2;
-                        axis(e0, s.dxy.x, ix, h.cell[0], c0, n0, 1, inc0, l0, tm0, td0);
-                        axis(e1, s.dxy.y, iy, h.cell[1], c1, n1, n0, inc1, l1, tm1, td1);
-                        axis(e2, s.dz, iz, h.cell[2], c2, n2, n0 * n1, inc2, l2, tm2, td2);
+                        axis(e0, s.dxy.x, ix, hc.x, c0, n0, 1, inc0, l0, tm0, td0);
+                        axis(e1, s.dxy.y, iy, hc.y, c1, n1, n0, inc1, l1, tm1, td1);
+                        axis(e2, s.dz, iz, hc.z, c2, n2, n0 * n1, inc2, l2, tm2, td2);
                         lin = (uint32_t)((c2 * n1 + c1) * n0 + c0);
                         rem = kGuard | l0 | l1 << 10 | l2 << 20;
                         // (Requesting this first range before the axis arithmetic and waiting after it -- inline-asm load -- was measured:

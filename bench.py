@@ -226,7 +226,19 @@ def extras(torch, apt, render, gen_data, cfg, sph, steps):
         p4 = apt.make_params(W, H, S, depth=D, num_spheres=ns4, accel=grid4.data_ptr())
         ms_full = timed(torch, lambda: render.render_frame(p4, scene4), 2)
         ms_ret = timed(torch, lambda: render.render_frame(p4.copy(flags=apt.APT_FLAG_RETIRE), scene4), 2)
+        # walk statistics from a separate, untimed launch at 64 spp (the counting instantiation of the kernel; per-segment averages do
+        # not depend on the sample count): cells visited and candidates tested per traced segment -> the EXECUTED work of a culled
+        # traversal, 20 flops per candidate test + 33 per segment (SURVEY 8(d)'s per-pair / per-segment counts), against the vector peak
+        with render.TraceCounter() as tc4:
+            render.render_frame(p4.copy(samples=16), scene4)
+        traced4, cells4, tests4 = tc4.stats
+        tps, cps = tests4 / max(traced4, 1), cells4 / max(traced4, 1)
+        flops_seg = 20.0 * tps + 33.0
+        achieved4 = nominal * flops_seg / (ms_full * 1e-3) / 1e12
         out["c4_grid_10k_spheres"] = {"kernel_ms": round(ms_full, 3), "retire_kernel_ms": round(ms_ret, 3), "nominal_mray_per_s": round(nominal / ms_full / 1e3, 1),
+                                      "tests_per_segment": round(tps, 2), "cells_per_segment": round(cps, 2),
+                                      "flops_per_segment_executed": round(flops_seg, 1), "achieved": round(achieved4, 3), "unit": "TFLOP/s",
+                                      "peak": PEAK_FP32_TFLOPS, "frac": round(achieved4 / PEAK_FP32_TFLOPS, 4), "bound": "valu",
                                       "kernel": "render_frame_queue8_kernel<..., grid> (pt_queue.h run_grid); frame bit-identical to the brute-force traversal"}
         del scene4, grid4
     except Exception as e:                   # noqa: BLE001
