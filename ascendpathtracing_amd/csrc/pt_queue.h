@@ -45,8 +45,10 @@ struct FrameArgs {
 #ifndef APT_Q8_POOL
 #define APT_Q8_POOL 64 // 64 entries (2 KB): measured against 128 in round 3 -- the LDS it frees is worth more occupancy (C5 -3 %)
 #endif
-constexpr uint32_t kPool = APT_Q8_POOL;  // ray pool entries per wave (power of two, >= kPoolBatch)
-constexpr uint32_t kPoolBatch = 64;      // rays generated at a time: one per lane
+// Ray pool entries per wave = rays generated at a time (one batch fills the empty pool).  The 8-sphere form: 64, one per lane (ray-generate is
+// a quarter of that kernel).  The grid form: 32 -- ray-generate is 2 % of a frame there, a half-empty generate pass costs nothing
+// measurable, and the 1024 bytes of LDS bring the wave to 6 granules of 1280 bytes instead of 7: 20 instead of 18 waves per CU.
+__host__ __device__ constexpr uint32_t queue_pool_entries(bool grid) { return grid ? 32u : (uint32_t)APT_Q8_POOL; }
 struct QueueArgs {
     uint32_t ppw;        // pixels per wave
     uint32_t nbuf;       // colour buffers = units that may be in flight (>= 2)
@@ -63,17 +65,17 @@ __host__ __device__ inline uint32_t queue_buf_bytes(uint32_t maxleaf) { return 4
 // bounce countdown, compact camera -- measured 16.24 against 16.06 ms at C2 with retirement, its two extra address instructions per
 // refill bought nothing.  Only the compact camera is kept.)
 constexpr uint32_t kQueueTabFloats4 = 16;                // 8 centres + 8 albedos (the grid form keeps its always-tested pair slots there)
-__host__ __device__ inline uint32_t queue_lds_off_tab() { return 2u * kPool * 16u; }
-__host__ __device__ inline uint32_t queue_lds_off_cam() { return queue_lds_off_tab() + kQueueTabFloats4 * 16u; }
-__host__ __device__ inline uint32_t queue_lds_off_key() { return queue_lds_off_cam() + (uint32_t)sizeof(CameraLite); }
+__host__ __device__ constexpr uint32_t queue_lds_off_tab(uint32_t pool) { return 2u * pool * 16u; }
+__host__ __device__ constexpr uint32_t queue_lds_off_cam(uint32_t pool) { return queue_lds_off_tab(pool) + kQueueTabFloats4 * 16u; }
+__host__ __device__ constexpr uint32_t queue_lds_off_key(uint32_t pool) { return queue_lds_off_cam(pool) + (uint32_t)sizeof(CameraLite); }
 // (with roulette: the HIGH words of the keys, 4 bytes per pool entry; the low word takes the place of the bounce countdown in pool_b, which
 // starts at depth - 1 for every ray and is not stored then -- 9072 -> 8816 bytes at S = 64: 7 instead of 8 LDS granules, 18 instead of 16 waves per CU)
-__host__ __device__ inline uint32_t queue_lds_off_stack(bool rr, uint32_t nbuf) { (void)nbuf; return queue_lds_off_key() + (rr ? kPool * 4u : 0u); }
-__host__ __device__ inline uint32_t queue_lds_off_colq(bool rr, uint32_t nbuf, bool stack) {
-    return queue_lds_off_stack(rr, nbuf) + (stack ? (uint32_t)kMaxStack * 3u * 4u * 4u : 0u);
+__host__ __device__ inline uint32_t queue_lds_off_stack(uint32_t pool, bool rr) { return queue_lds_off_key(pool) + (rr ? pool * 4u : 0u); }
+__host__ __device__ inline uint32_t queue_lds_off_colq(uint32_t pool, bool rr, bool stack) {
+    return queue_lds_off_stack(pool, rr) + (stack ? (uint32_t)kMaxStack * 3u * 4u * 4u : 0u);
 }
-__host__ __device__ inline uint32_t queue_lds_bytes(bool rr, uint32_t nbuf, bool stack, uint32_t buf_bytes) {
-    return queue_lds_off_colq(rr, nbuf, stack) + nbuf * buf_bytes;
+__host__ __device__ inline uint32_t queue_lds_bytes(uint32_t pool, bool rr, uint32_t nbuf, bool stack, uint32_t buf_bytes) {
+    return queue_lds_off_colq(pool, rr, stack) + nbuf * buf_bytes;
 }
 
 #ifndef APT_QUEUE8_WAVES
@@ -92,8 +94,9 @@ template <int MODE, bool RR, int SC = kScene8, bool STATS = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SC == kSceneGrid ? APT_QUEUE_GRID_WAVES : APT_QUEUE8_WAVES, SC == kSceneGrid ? APT_QUEUE_GRID_WAVES : APT_QUEUE8_WAVES))) void render_frame_queue8_kernel(const float *__restrict__ sph, FrameArgs fa, TraceArgs ta,
                                                                  LeafProg lp, QueueArgs qa) {
     extern __shared__ __align__(16) unsigned char qlds[];
-    float4 *tab = reinterpret_cast<float4 *>(qlds + queue_lds_off_tab());
-    CameraLite &cam = *reinterpret_cast<CameraLite *>(qlds + queue_lds_off_cam());
+    constexpr uint32_t kPool = queue_pool_entries(SC == kSceneGrid), kPoolBatch = kPool;
+    float4 *tab = reinterpret_cast<float4 *>(qlds + queue_lds_off_tab(kPool));
+    CameraLite &cam = *reinterpret_cast<CameraLite *>(qlds + queue_lds_off_cam(kPool));
     const uint32_t lane = threadIdx.x;
     // No static LDS in this kernel, so the dynamic region starts at LDS address 0 (tests/test_isa_hazards.py checks the kernel
     // descriptor's group_segment_fixed_size); a build that breaks this renders nothing rather than reading the wrong pool entries.
@@ -112,9 +115,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SC == kScene
 
     float4 *pool_a = reinterpret_cast<float4 *>(qlds);                 // (ox, oy, dx, dy)
     float4 *pool_b = pool_a + kPool;                                   // (oz, dz, colour address, bounce countdown)
-    uint32_t *pool_keyhi = reinterpret_cast<uint32_t *>(qlds + queue_lds_off_key());     // Russian-roulette key, high word (APT_FLAG_RR only; low word: pool_b[.].w)
-    float *stack = reinterpret_cast<float *>(qlds + queue_lds_off_stack(rr, nbuf));      // [kMaxStack][3][4] when nleaves > 1
-    const uint32_t colq_off = queue_lds_off_colq(rr, nbuf, nleaves > 1);
+    uint32_t *pool_keyhi = reinterpret_cast<uint32_t *>(qlds + queue_lds_off_key(kPool));     // Russian-roulette key, high word (APT_FLAG_RR only; low word: pool_b[.].w)
+    float *stack = reinterpret_cast<float *>(qlds + queue_lds_off_stack(kPool, rr));     // [kMaxStack][3][4] when nleaves > 1
+    const uint32_t colq_off = queue_lds_off_colq(kPool, rr, nleaves > 1);
     unsigned char *colq = qlds + colq_off;                              // [nbuf][items][3] floats
     constexpr uint32_t qlds_base = 0u;                                  // LDS byte address of the dynamic region (checked above)
     __syncthreads();
@@ -338,7 +341,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SC == kScene
                              : [sv] "=&s"(saved), [oxy] "+v"(st.oxy), [dxy] "+v"(st.dxy), [oz] "+v"(st.oz), [dz] "+v"(st.dz), [ca] "+v"(caddr),
                                [lf] "+v"(left), [rxy] "+v"(thr_xy), [rz] "+v"(thr_z), [kl] "+v"(klo), [kh] "+v"(khi)
                              : [m] "s"(take), [ea] "v"(ea), [eh] "v"(eh), [l0] "s"(ta.depth - 1u), [ob0] "n"(kPool * 16u), [ob1] "n"(kPool * 16u + 4u),
-                               [ob2] "n"(kPool * 16u + 8u), [ob3] "n"(kPool * 16u + 12u), [okh] "n"(2u * kPool * 16u + kQueueTabFloats4 * 16u + (uint32_t)sizeof(CameraLite))
+                               [ob2] "n"(kPool * 16u + 8u), [ob3] "n"(kPool * 16u + 12u), [okh] "n"(queue_lds_off_key(kPool))
                              : "scc", "memory");
                 key = ((uint64_t)khi << 32) | klo;
             }

@@ -163,8 +163,8 @@ int do_render_paths(const Launch &ls, const apt_render_params *p, void *stream, 
 }
 
 // The sample-queue kernels' launch shape (pt_queue.h): colour buffers, pixels per wave, dynamic LDS.  -> false: too many waves.
-bool queue_launch_shape(const apt::Debug &dbg, const LeafProg &lp, bool rr, uint64_t pixel_count, bool retire, QueueArgs &qa, uint64_t &waves,
-                        size_t &qlds) {
+bool queue_launch_shape(const apt::Debug &dbg, const LeafProg &lp, bool rr, bool grid, uint64_t pixel_count, bool retire, QueueArgs &qa,
+                        uint64_t &waves, size_t &qlds) {
     const uint32_t unit_items = 4u * lp.maxleaf;
     qa.nbuf = dbg.queue_nbuf ? dbg.queue_nbuf : std::max(2u, std::min(16u, (512u + unit_items - 1u) / unit_items));
     qa.buf_bytes = queue_buf_bytes(lp.maxleaf);
@@ -174,7 +174,7 @@ bool queue_launch_shape(const apt::Debug &dbg, const LeafProg &lp, bool rr, uint
     const uint64_t ppw = dbg.queue_ppw ? dbg.queue_ppw : std::max<uint64_t>(4, std::min<uint64_t>(16, pixel_count / 8192u));
     qa.ppw = (uint32_t)ppw;
     waves = (pixel_count + ppw - 1) / ppw;
-    qlds = queue_lds_bytes(rr, qa.nbuf, lp.nleaves > 1, qa.buf_bytes) + dbg.queue_lds_pad;   // the pad: experiments only, lowers the occupancy
+    qlds = queue_lds_bytes(queue_pool_entries(grid), rr, qa.nbuf, lp.nleaves > 1, qa.buf_bytes) + dbg.queue_lds_pad;   // the pad: experiments only, lowers the occupancy
     return waves <= 0x7fffffffull;
 }
 
@@ -207,7 +207,7 @@ int do_render_frame(const Launch &ls, const apt_render_params *p, void *stream, 
         uint64_t waves;
         size_t qlds;
         const bool rrk = ta.rr_start != 0;
-        if (!queue_launch_shape(dbg, lp, rrk, pixel_count, true, qa, waves, qlds)) return fail(APT_ERR_ARG, "pixel_count too large for one launch; shard it%s");
+        if (!queue_launch_shape(dbg, lp, rrk, false, pixel_count, true, qa, waves, qlds)) return fail(APT_ERR_ARG, "pixel_count too large for one launch; shard it%s");
         if (p->mode == APT_MODE_ORACLE) {
             if (rrk) hipLaunchKernelGGL((render_frame_queue8_kernel<kModeOracle, true>), dim3((unsigned)waves), dim3(64), qlds, st, spheres, fa, ta, lp, qa);
             else hipLaunchKernelGGL((render_frame_queue8_kernel<kModeOracle, false>), dim3((unsigned)waves), dim3(64), qlds, st, spheres, fa, ta, lp, qa);
@@ -228,7 +228,7 @@ int do_render_frame(const Launch &ls, const apt_render_params *p, void *stream, 
         uint64_t waves;
         size_t qlds;
         const bool rrk = ta.rr_start != 0;
-        if (!queue_launch_shape(dbg, lp, rrk, pixel_count, retire, qa, waves, qlds)) return fail(APT_ERR_ARG, "pixel_count too large for one launch; shard it%s");
+        if (!queue_launch_shape(dbg, lp, rrk, true, pixel_count, retire, qa, waves, qlds)) return fail(APT_ERR_ARG, "pixel_count too large for one launch; shard it%s");
         // (the walk statistics behind apt_set_trace_counter are a template flag: a frame without a counter does not carry them)
         const bool oracle = p->mode == APT_MODE_ORACLE, stats = ta.traced != nullptr;
         const dim3 qgrid((unsigned)waves), qblock(64);
