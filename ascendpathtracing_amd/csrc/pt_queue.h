@@ -11,8 +11,9 @@
 //     pairwise leaf of one pixel = 4 sub-pixels x n <= 128 samples); nothing is drained between units, so the only
 //     idle lanes are those of the wave's very last unit;
 //   * ray-generate (float64, ~230 VALU instructions per ray) is decoupled from tracing through a per-wave LDS RAY
-//     POOL (64 entries x 32 bytes, FIFO): when it is empty the wave generates 64 consecutive items with all 64 lanes,
-//     whatever the lanes' paths are doing (and serves the lanes that the pool's last entries could not serve);
+//     POOL (64 entries x 32 bytes, FIFO; 32 entries in the grid form): when it is empty the wave generates a pool's worth
+//     of consecutive items, one per lane, whatever the lanes' paths are doing (and serves the lanes that the pool's last
+//     entries could not serve);
 //   * after every bounce the lanes whose path is finished (alive bit cleared, throughput zero, depth reached: wave
 //     masks on the scalar unit) park their throughput in the unit's colour buffer in LDS and take the next pool
 //     entries: ballot -> mbcnt rank -> one exec-masked block of ds_reads straight into the path-state registers;
@@ -26,6 +27,8 @@
 //
 // The arithmetic of a bounce is bounce_ns8_v2 (pt_trace.h), the accumulation order is numpy's: the frame is bit-identical
 // to the full-trace kernel's and to the CPU restatement's, and the traced-segment count equals the oracle's.
+// A wave whose loop bound trips (a logic error; never seen) or whose LDS does not start at address 0 says so through the context's
+// device status word (include/render_mi355x.h APT_DEV_*; the reference asserts inside its kernel, src/render.cpp:68-73).
 #pragma once
 #include <type_traits>
 

@@ -126,6 +126,7 @@ int main(int argc, char **argv) {
         std::vector<uint8_t> u8(npix * 3);
         CHECK_HIP(hipMemcpyAsync(u8.data(), u8Dev, u8.size(), hipMemcpyDeviceToHost, stream));
         CHECK_HIP(hipStreamSynchronize(stream));
+        if (apt_check(stream) != APT_OK) { fprintf(stderr, "[ERROR]  %s\n", apt_last_error()); return 4; }   // the kernel-side ASSERT (render.cpp:68-73)
         if (apt_write_ppm("./output/color.ppm", prm.width, prm.height, u8.data()) != APT_OK) return 5;
         CHECK_HIP(hipFree(fbDev)); CHECK_HIP(hipFree(u8Dev));
     } else {
@@ -139,6 +140,7 @@ int main(int argc, char **argv) {
         render_do(blockDim, nullptr, stream, (uint8_t *)rayDev, (uint8_t *)sphDev, (uint8_t *)colDev); // main.cpp:74
         if (apt_last_status() != APT_OK) { fprintf(stderr, "[ERROR]  %s\n", apt_last_error()); return 4; }
         CHECK_HIP(hipStreamSynchronize(stream));                              // main.cpp:75
+        if (apt_check(stream) != APT_OK) { fprintf(stderr, "[ERROR]  %s\n", apt_last_error()); return 4; }   // the kernel-side ASSERT (render.cpp:68-73)
         CHECK_HIP(hipMemcpy(colHost.data(), colDev, colBytes, hipMemcpyDeviceToHost)); // main.cpp:77
         if (!write_file("./output/color.bin", colHost.data(), colBytes)) return 5;     // main.cpp:79
         CHECK_HIP(hipFree(rayDev)); CHECK_HIP(hipFree(colDev));
