@@ -84,6 +84,10 @@ CASES = {
                       ranges=[[(k * 2654435761 + 12345) % (4096 * 4096 - 1024), 1024] for k in range(64)]),
     "C4_1080p_spread": dict(w=1920, h=1080, s=64, depth=8, mode="K", flags=0, seed=0, scene=("scene", 10000, 1),
                             ranges=[[(k * 40503 * 4099 + 977) % (1920 * 1080 - 128), 128] for k in range(64)]),
+    # Round 4 (the C4 frame was oracle-pinned on 10 240 of its 2 073 600 pixels): 384 more ranges of 256 pixels,
+    # 98 304 pixels = 4.7 % of the frame, ~1.5 hours of brute force over 10 000 spheres on 6 threads
+    "C4_1080p_spread2": dict(w=1920, h=1080, s=64, depth=8, mode="K", flags=0, seed=0, scene=("scene", 10000, 1),
+                             ranges=[[(k * 2246822519 + 3266489917) % (1920 * 1080 - 256), 256] for k in range(384)]),
 }
 
 

@@ -9,6 +9,7 @@ tests/golden/make_fullsize_hashes.py).  Always on under -m gpu: the whole file c
     C3_band5_whole / C3_spread (round 3)                          ALL 2^21 pixels of rank band 5; 64 ranges of 1024 pixels
                                                                   spread over the whole frame (every band's interior)
     C4_1080p_spread (round 3)                                     64 more ranges of the 10 000-sphere 1080p frame
+    C4_1080p_spread2 (round 4)                                    384 more ranges of 256 pixels of it (4.7 % of the frame)
     C4_*      10 000-sphere scene                                 a whole 480x270 frame (brute force and grid) and
                                                                   ranges of the 1080p / 256 spp frame (grid)
 The CPU test at the bottom re-runs the oracle on a few ranges so that the committed file cannot drift from it.
@@ -148,6 +149,7 @@ def test_c4_ten_thousand_spheres(apt):
     torch.cuda.synchronize()
     _check_ranges(case, fb, u8, 0, "C4 1080p grid")
     _check_ranges(HASHES["C4_1080p_spread"], fb, u8, 0, "C4 1080p grid, 64 more ranges")
+    _check_ranges(HASHES["C4_1080p_spread2"], fb, u8, 0, "C4 1080p grid, 384 more ranges (round 4: 98 304 pixels)")
     for b, c in case["ranges"]:
         fb, u8 = apt.render.render_frame(_params(apt, case, ns), sph, b, c)
         torch.cuda.synchronize()
