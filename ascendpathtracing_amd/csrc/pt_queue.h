@@ -243,21 +243,24 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SC == kScene
             for (int ch = 0; ch < 3; ++ch) res[ch] = stack[ch * 4 + sub];
         }
         if (a_leaf + 1 == nleaves) {                                    // decode_color: data_visualization.py:36-57
+            // The lanes of a group hold equal sums for all three channels: lane j of a group decodes channel j (j < 3; the others repeat
+            // channel 0), so the divide, the float64 mean of the four sub-pixels and the clamp run ONCE per pixel instead of once per channel
+            // (round 4: ~60 of the ~205 vector instructions a wave spends per pixel outside the bounces; C2 with retirement 16.0 -> 15.75 ms.
+            // Going further -- the lower half of the wave summing (r, g) as packed pairs, the upper half b -- measured no faster.)
             const float fs = (float)S;
             const uint64_t pl = wb + a_px;
-            const int gbase = (int)(lane & ~31u);
+            const int src0 = (int)((lane & ~31u) + j);                  // the lane with this channel in sub-pixel group 0 of this half of the wave
+            const uint32_t ch = j < 3u ? j : 0u;
+            const float r = j == 1u ? res[1] : (j == 2u ? res[2] : res[0]);
+            const float mean = r / fs;                                  // np.mean: float32 sum / count
+            double a64 = 0.0;                                           // :38 sum_color = zeros (float64)
 #pragma unroll
-            for (int ch = 0; ch < 3; ++ch) {
-                const float mean = res[ch] / fs;                        // np.mean: float32 sum / count
-                double a64 = 0.0;                                       // :38 sum_color = zeros (float64)
-#pragma unroll
-                for (int sq = 0; sq < 4; ++sq) a64 = a64 + (double)__shfl(mean, gbase + sq * 8, 64); // :41-45
-                const double v = a64 / 4;                               // :46
-                const double cl = v < 0 ? 0 : (v > 1 ? 1 : v);          // :54
-                if (lane == 0) {
-                    fa.fb[(uint64_t)ch * fa.pixel_count + pl] = (float)cl;
-                    if (fa.fb_u8) fa.fb_u8[pl * 3 + ch] = (uint8_t)(cl * 255); // :55-57 truncation
-                }
+            for (int sq = 0; sq < 4; ++sq) a64 = a64 + (double)__shfl(mean, src0 + sq * 8, 64); // :41-45
+            const double v = a64 / 4;                                   // :46
+            const double cl = v < 0 ? 0 : (v > 1 ? 1 : v);              // :54
+            if (lane < 3u) {
+                fa.fb[(uint64_t)ch * fa.pixel_count + pl] = (float)cl;
+                if (fa.fb_u8) fa.fb_u8[pl * 3 + ch] = (uint8_t)(cl * 255); // :55-57 truncation
             }
             a_sp = 0;
         }
