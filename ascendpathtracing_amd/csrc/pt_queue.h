@@ -175,7 +175,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SC == kScene
             pool_a[e] = make_float4(rox, roy, rdx, rdy);
             const uint32_t ca = qlds_base + colq_off + g_buf * qa.buf_bytes + i * 12u + sub * 4u;
             if (rr) {
-                const uint64_t k64 = rr_path_key(ta.seed, path);
+                // what the roulette of this path hashes at shading bounce d is splitmix64(key + phi * (d + 1)), and splitmix64 starts by adding
+                // phi: the entry carries key + phi * rr_start, the state one step before the path's first roulette (d = rr_start - 1), and
+                // roulette() below advances it by phi per draw -- no 64-bit multiply per bounce
+                const uint64_t k64 = rr_path_key(ta.seed, path) + 0x9E3779B97F4A7C15ull * (uint64_t)ta.rr_start;
                 pool_b[e] = make_float4(roz, rdz, __uint_as_float(ca), __uint_as_float((uint32_t)k64));
                 pool_keyhi[e] = (uint32_t)(k64 >> 32);
             } else {
@@ -359,20 +362,65 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SC == kScene
             alive |= take;
         }
     };
+    // ---- Russian roulette (include/render_mi355x.h APT_FLAG_RR; pt_core.h russian_roulette() is the per-lane form) for the lanes of `m`, which
+    // have just shaded bounce d = depth - 1 - left (the countdown started at depth - 1).  Wave-level form: which lanes draw is a scalar mask
+    // (d + 1 >= rr_start, alive, largest throughput component > 0), everything else runs unmasked -- an instruction costs its issue slot
+    // whatever the mask -- and only the two writes are exec-masked: no nested divergent branches (the per-lane form compiled to four levels
+    // of them), the hash input by one 64-bit add from the running state (see gen_batch), max3 for the largest component, the 24-bit draw
+    // by a 32-bit conversion: ~35 instead of ~55 vector instructions per loop turn, same operations on the same values.
+    auto roulette = [&](uint64_t m) __attribute__((always_inline)) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        const int deep_left = (int)ta.depth - (int)ta.rr_start;         // d + 1 >= rr_start  <=>  left <= depth - rr_start
+        const uint64_t m1 = m & __builtin_amdgcn_ballot_w64((int)left <= deep_left);
+        if (m1 == 0) return;                                            // wave-uniform
+        uint64_t saved;
+        asm volatile("s_and_saveexec_b64 %[sv], %[m]\n\t"
+                     "v_lshl_add_u64 %[k], %[k], 0, %[phi]\n\t"
+                     "s_mov_b64 exec, %[sv]"
+                     : [sv] "=&s"(saved), [k] "+v"(key)
+                     : [m] "s"(m1), [phi] "s"(0x9E3779B97F4A7C15ull)
+                     : "scc");
+        uint64_t x = key;                                               // splitmix64 after its first addition
+        x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+        x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+        const uint32_t hi = (uint32_t)(x >> 32);
+        const uint32_t draw = (hi ^ (hi >> 31)) >> 8;                   // the 24 high bits of x ^ (x >> 31)
+        float uf;
+        asm("v_cvt_f32_u32 %0, %1" : "=v"(uf) : "v"(draw));
+        const float u = uf * 0x1p-24f;
+        // q = rx; if (ry > q) q = ry; if (rz > q) q = rz: the largest component with NaNs in ry / rz ignored -- v_max3 --, and NaN when rx is
+        float q;
+        asm("v_max3_f32 %0, %1, %2, %3" : "=v"(q) : "v"(thr_xy.x), "v"(thr_xy.y), "v"(thr_z));
+        const uint64_t draws = m1 & alive & __builtin_amdgcn_ballot_w64(q > 0.0f) & __builtin_amdgcn_ballot_w64(thr_xy.x == thr_xy.x);
+        const float p = __builtin_amdgcn_fmed3f(q, 0.05f, 0.95f);
+        const uint64_t dies = __builtin_amdgcn_ballot_w64(u >= p);
+        const float r0 = __builtin_amdgcn_rcpf(p);                      // 1 / p, correctly rounded (russian_roulette's sequence)
+        const float e0 = __builtin_fmaf(-p, r0, 1.0f);
+        const float r1 = __builtin_fmaf(e0, r0, r0);
+        float e = __builtin_fmaf(-p, r1, 1.0f);
+        const float q1 = __builtin_fmaf(e, r1, r1);
+        e = __builtin_fmaf(-p, q1, 1.0f);
+        const float inv = __builtin_fmaf(e, r1, q1);
+        const uint64_t lives = draws & ~dies, killed = draws & dies;
+        f2 inv2;                                                        // (the packed product reads the first half twice: op_sel_hi)
+        inv2.x = inv;
+        asm volatile("s_and_saveexec_b64 %[sv], %[ml]\n\t"
+                     "v_pk_mul_f32 %[rxy], %[rxy], %[inv] op_sel_hi:[1,0]\n\t"
+                     "v_mul_f32 %[rz], %[rz], %[inv1]\n\t"
+                     "s_mov_b64 exec, %[mk]\n\t"
+                     "v_mov_b64 %[rxy], 0\n\t"
+                     "v_mov_b32 %[rz], 0\n\t"
+                     "s_mov_b64 exec, %[sv]"
+                     : [sv] "=&s"(saved), [rxy] "+v"(thr_xy), [rz] "+v"(thr_z)
+                     : [ml] "s"(lives), [mk] "s"(killed), [inv] "v"(inv2), [inv1] "v"(inv)
+                     : "scc");
+#endif
+    };
     // ---- bookkeeping after a bounce that stands ------------------------------------------------------------------
     auto post_bounce = [&]() __attribute__((always_inline)) {
         ++n_bounce_exec;
         traced += (uint32_t)__popcll(active);
-        if (rr) {   // roulette after shading bounce d (0-based) when d + 1 >= rr_start; the countdown started at depth - 1
-            const uint32_t d = ta.depth - 1u - left;
-            const bool on = select_const(active, 1) != 0 && d + 1u >= ta.rr_start;
-            if (on) {
-                PathState t;
-                t.rxy = thr_xy; t.rz = thr_z; t.alive = select_const(alive, 1);
-                russian_roulette(t, key, d);
-                thr_xy = t.rxy; thr_z = t.rz;
-            }
-        }
+        if (rr) roulette(active);
     };
     // One bounce of the wave, in place.  Idle lanes compute on stale state: whatever they hold is overwritten when they take
     // their next ray.  The bounce runs in two phases (pt_trace.h bounce_ns8_v2_hit / _reflect): whether a lane whose path can still
@@ -753,15 +801,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SC == kScene
             // lanes of `fin` still alive after this bounce
             alive &= ~(fin & __builtin_amdgcn_ballot_w64(is_light));
             apply_albedo(thr_xy, thr_z, alb, alive & fin);
-            if (rr) {
-                const uint32_t d = ta.depth - 1u - left;
-                if (lane_in(fin) && d + 1u >= ta.rr_start) {
-                    PathState t;
-                    t.rxy = thr_xy; t.rz = thr_z; t.alive = select_const(alive, 1);
-                    russian_roulette(t, key, d);
-                    thr_xy = t.rxy; thr_z = t.rz;
-                }
-            }
+            if (rr) roulette(fin);
             {   // park the finished paths of `fin` (park() of the 8-sphere form, restricted to these lanes)
                 uint64_t zero, at_depth, saved;
                 uint32_t orbits;
