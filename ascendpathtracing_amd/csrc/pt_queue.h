@@ -673,9 +673,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SC == kScene
                     pend = kNoPos;
                 }
             }
-            bestk = take ? m2 : bestk;
             bestp = take ? psel : bestp;
             if (TIES) pend = take ? kNoPos : (tie ? psel : pend);
+            bestk = min(bestk, m2);                             // (last: the compares above read the old minimum)
 #else
             const bool eq_a = TIES && ma == bestk, eq_b = TIES && mb == bestk && !eq_a, tie = eq_a || eq_b;
             if (TIES && __builtin_expect(__builtin_amdgcn_ballot_w64(tie && pend != kNoPos) != 0, 0)) {
@@ -711,19 +711,25 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SC == kScene
                 if (need) {
                     const float te = fminf(tm0, fminf(tm1, tm2));                   // parameter at which the ray leaves this cell
                     const float tmin = bits_f32(bestk + kbias);
-                    const bool s0 = tm0 <= tm1 && tm0 <= tm2, s1 = !s0 && tm1 <= tm2;
-                    tm0 = s0 ? tm0 + td0 : tm0;
-                    tm1 = s1 ? tm1 + td1 : tm1;
-                    tm2 = (!s0 && !s1) ? tm2 + td2 : tm2;
-                    {   // lin += s0 ? inc0 : (s1 ? inc1 : inc2), written with explicit masks: the plain nested select of the three
-                        // per-lane increments ends in "illegal VGPR to SGPR copy" in this compiler's back end
-                        const uint64_t m0 = __builtin_amdgcn_ballot_w64(s0), m1 = __builtin_amdgcn_ballot_w64(s1);
-                        uint32_t sel;
+                    // which axis is crossed: masks straight from the three compares (a ballot of the combined bool went through a 0 / 1
+                    // register and a second compare: 4 vector instructions per turn)
+                    const uint64_t b01 = __builtin_amdgcn_ballot_w64(tm0 <= tm1), b02 = __builtin_amdgcn_ballot_w64(tm0 <= tm2),
+                                   b12 = __builtin_amdgcn_ballot_w64(tm1 <= tm2);
+                    const uint64_t m0 = b01 & b02, m1 = ~m0 & b12, m01 = m0 | m1;
+                    {
+                        const float a0 = tm0 + td0, a1 = tm1 + td1, a2 = tm2 + td2;
+                        asm("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(tm0) : "v"(a0), "s"(m0));
+                        asm("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(tm1) : "v"(a1), "s"(m1));
+                        asm("v_cndmask_b32_e64 %0, %1, %0, %2" : "+v"(tm2) : "v"(a2), "s"(m01));
+                        // lin += axis 0 ? inc0 : (axis 1 ? inc1 : inc2); steps left: one less in the axis' 10-bit field (shift 0 / 10 / 20: inline constants)
+                        uint32_t sel, sh;
                         asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(sel) : "v"(inc2), "v"(inc1), "s"(m1));
                         asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(sel) : "v"(sel), "v"(inc0), "s"(m0));
                         lin += sel;
+                        asm("v_cndmask_b32_e64 %0, 20, 10, %1" : "=v"(sh) : "s"(m1));
+                        asm("v_cndmask_b32_e64 %0, %1, 0, %2" : "=v"(sh) : "v"(sh), "s"(m0));
+                        rem -= 1u << sh;
                     }
-                    rem -= s0 ? 1u : (s1 ? 1u << 10 : 1u << 20);
                     // nothing nearer can lie ahead, or the next cell is outside the grid (an axis with no steps left lost its guard bit)
                     stop = tmin < te - (1e-3f * fabsf(te) + walk_margin) || (rem & kGuard) != kGuard;
                     if (!stop) fetch_range();
@@ -732,7 +738,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SC == kScene
             const bool has = w && !stop && cur < end;
             {
                 if (has) {
-                    const float4 a = slot_geom[cur], c4 = slot_geom[cur + 1u];   // slot cur / 2: float4s 2 * slot and 2 * slot + 1
+                    // slot cur / 2: float4s 2 * slot and 2 * slot + 1, by a 32-bit byte offset from the table's (scalar) base (positions have 27 bits)
+                    const float4 *sg = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(slot_geom) + (cur << 4));
+                    const float4 a = sg[0], c4 = sg[1];
                     test_pair(a, c4, cur, std::true_type{});
                     cur += 2u;
                     if (STATS) n_tests += 2;
