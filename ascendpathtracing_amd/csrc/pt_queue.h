@@ -665,7 +665,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SC == kScene
             // both candidates with the running minimum in turn: 4 more vector instructions per slot.)
             const bool isb = mb < ma;
             const uint32_t m2 = isb ? mb : ma;
-            const uint32_t psel = pos + (isb ? 1u : 0u);
+            const uint32_t psel = isb ? pos + 1u : pos;            // (a select of two inline constants in the always-tested list, an add-with-carry in the walk)
             const bool take = m2 < bestk, tie = TIES && m2 == bestk;
             if (TIES && __builtin_expect(__builtin_amdgcn_ballot_w64(tie && pend != kNoPos) != 0, 0)) {
                 if (tie && pend != kNoPos) {
@@ -703,41 +703,67 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SC == kScene
             if (STATS) ++n_cells;
         };
         // ---- one turn of the walking lanes ----
+        // Written in wave masks: which lanes leave their cell, which stop, which test a slot are scalar values, the branches around the two
+        // halves are wave-uniform and the per-lane updates are selects on those masks or exec-masked instructions.  (The first form put the
+        // halves in divergent `if`s: every mask -> bool -> mask round trip is a v_cndmask + v_cmp pair, five of them per turn.)
         auto turn = [&]() __attribute__((always_inline)) {
-            bool stop = false;                                  // (wave masks are only updated outside divergent regions)
-            const bool w = lane_in(walking);
-            const bool need = w && cur >= end;                  // list exhausted: leave the cell
-            {
-                if (need) {
-                    const float te = fminf(tm0, fminf(tm1, tm2));                   // parameter at which the ray leaves this cell
-                    const float tmin = bits_f32(bestk + kbias);
-                    // which axis is crossed: masks straight from the three compares (a ballot of the combined bool went through a 0 / 1
-                    // register and a second compare: 4 vector instructions per turn)
-                    const uint64_t b01 = __builtin_amdgcn_ballot_w64(tm0 <= tm1), b02 = __builtin_amdgcn_ballot_w64(tm0 <= tm2),
-                                   b12 = __builtin_amdgcn_ballot_w64(tm1 <= tm2);
-                    const uint64_t m0 = b01 & b02, m1 = ~m0 & b12, m01 = m0 | m1;
-                    {
-                        const float a0 = tm0 + td0, a1 = tm1 + td1, a2 = tm2 + td2;
-                        asm("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(tm0) : "v"(a0), "s"(m0));
-                        asm("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(tm1) : "v"(a1), "s"(m1));
-                        asm("v_cndmask_b32_e64 %0, %1, %0, %2" : "+v"(tm2) : "v"(a2), "s"(m01));
-                        // lin += axis 0 ? inc0 : (axis 1 ? inc1 : inc2); steps left: one less in the axis' 10-bit field (shift 0 / 10 / 20: inline constants)
-                        uint32_t sel, sh;
-                        asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(sel) : "v"(inc2), "v"(inc1), "s"(m1));
-                        asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(sel) : "v"(sel), "v"(inc0), "s"(m0));
-                        lin += sel;
-                        asm("v_cndmask_b32_e64 %0, 20, 10, %1" : "=v"(sh) : "s"(m1));
-                        asm("v_cndmask_b32_e64 %0, %1, 0, %2" : "=v"(sh) : "v"(sh), "s"(m0));
-                        rem -= 1u << sh;
-                    }
-                    // nothing nearer can lie ahead, or the next cell is outside the grid (an axis with no steps left lost its guard bit)
-                    stop = tmin < te - (1e-3f * fabsf(te) + walk_margin) || (rem & kGuard) != kGuard;
-                    if (!stop) fetch_range();
+            const uint64_t need = walking & __builtin_amdgcn_ballot_w64(cur >= end);     // list exhausted: leave the cell
+            uint64_t stopm = 0;
+            if (need != 0) {
+                const float te = fminf(tm0, fminf(tm1, tm2));                           // parameter at which the ray leaves this cell
+                const float tmin = bits_f32(bestk + kbias);
+                // which axis is crossed: masks straight from the three compares
+                const uint64_t b01 = __builtin_amdgcn_ballot_w64(tm0 <= tm1), b02 = __builtin_amdgcn_ballot_w64(tm0 <= tm2),
+                               b12 = __builtin_amdgcn_ballot_w64(tm1 <= tm2);
+                const uint64_t x0 = b01 & b02, m0 = x0 & need, m1 = ~x0 & b12 & need, m2 = need & ~(x0 | b12);
+                const float a0 = tm0 + td0, a1 = tm1 + td1, a2 = tm2 + td2;
+                asm("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(tm0) : "v"(a0), "s"(m0));
+                asm("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(tm1) : "v"(a1), "s"(m1));
+                asm("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(tm2) : "v"(a2), "s"(m2));
+                // lin += axis 0 ? inc0 : (axis 1 ? inc1 : inc2); steps left: one less in the axis' 10-bit field (shift 0 / 10 / 20: inline constants)
+                uint32_t sel, sh;
+                asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(sel) : "v"(inc2), "v"(inc1), "s"(m1));
+                asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(sel) : "v"(sel), "v"(inc0), "s"(m0));
+                asm("v_cndmask_b32_e64 %0, 20, 10, %1" : "=v"(sh) : "s"(m1));
+                asm("v_cndmask_b32_e64 %0, %1, 0, %2" : "=v"(sh) : "v"(sh), "s"(m0));
+                const uint32_t dec = 1u << sh;
+                uint64_t saved;
+                asm volatile("s_and_saveexec_b64 %[sv], %[m]\n\t"
+                             "v_add_u32 %[lin], %[lin], %[sel]\n\t"
+                             "v_sub_u32 %[rem], %[rem], %[dec]\n\t"
+                             "s_mov_b64 exec, %[sv]"
+                             : [sv] "=&s"(saved), [lin] "+v"(lin), [rem] "+v"(rem)
+                             : [m] "s"(need), [sel] "v"(sel), [dec] "v"(dec)
+                             : "scc");
+                // nothing nearer can lie ahead, or the next cell is outside the grid (an axis with no steps left lost its guard bit)
+                stopm = need & (__builtin_amdgcn_ballot_w64(tmin < te - (1e-3f * fabsf(te) + walk_margin)) |
+                                __builtin_amdgcn_ballot_w64((rem & kGuard) != kGuard));
+                const uint64_t go = need & ~stopm;
+                // cellslot[lin] -> the next cell's POSITION range (fetch_range()), for the lanes of `go`; the value is needed at once
+                uint32_t cnt;
+                asm volatile("s_and_saveexec_b64 %[sv], %[m]\n\t"
+                             "v_lshlrev_b32 %[cnt], 2, %[lin]\n\t"
+                             "global_load_dword %[cnt], %[cnt], %[base]\n\t"
+                             "s_waitcnt vmcnt(0)\n\t"
+                             "v_lshrrev_b32 %[cur], 5, %[cnt]\n\t"
+                             "v_and_b32 %[cur], 0x7fffffe, %[cur]\n\t"
+                             "v_and_b32 %[cnt], 63, %[cnt]\n\t"
+                             "v_lshl_add_u32 %[end], %[cnt], 1, %[cur]\n\t"
+                             "s_mov_b64 exec, %[sv]"
+                             : [sv] "=&s"(saved), [cur] "+v"(cur), [end] "+v"(end), [cnt] "=&v"(cnt)
+                             : [m] "s"(go), [lin] "v"(lin), [base] "s"(cellslot)
+                             : "scc", "memory");
+                static_assert(kGridSlotCountBits == 6 && kGridSlotCountMax == 63, "the shifts and masks of the block above");
+                const uint64_t longl = go & __builtin_amdgcn_ballot_w64(cnt == kGridSlotCountMax);
+                if (__builtin_expect(longl != 0, 0)) {           // a long list (clustered scenes): the count from cell_start
+                    if (lane_in(longl)) end = cur + 2u * ((cell_start[lin + 1] - cell_start[lin] + 1u) >> 1);
                 }
+                if (STATS) n_cells += select_const(go, 1);
+                walking &= ~stopm;
             }
-            const bool has = w && !stop && cur < end;
-            {
-                if (has) {
+            const uint64_t has = walking & __builtin_amdgcn_ballot_w64(cur < end);
+            if (has != 0) {
+                if (lane_in(has)) {
                     // slot cur / 2: float4s 2 * slot and 2 * slot + 1, by a 32-bit byte offset from the table's (scalar) base (positions have 27 bits)
                     const float4 *sg = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(slot_geom) + (cur << 4));
                     const float4 a = sg[0], c4 = sg[1];
@@ -746,7 +772,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SC == kScene
                     if (STATS) n_tests += 2;
                 }
             }
-            walking &= ~__builtin_amdgcn_ballot_w64(stop);
         };
         // ---- the per-segment block for the lanes of `batch` (none of them walking): finish the segment they hold, park / refill,
         // start the next one ----
@@ -755,18 +780,21 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SC == kScene
             const uint64_t fin = batch & has_seg & active;     // lanes whose finished segment is shaded now
             traced += (uint32_t)__popcll(fin);
             bool is_light = false;                             // (wave masks are only formed outside divergent regions)
-            Albedo alb = {f2{1.0f, 1.0f}, 1.0f};
+            Albedo alb;                                        // only read under exec = alive & fin (apply_albedo below): no default needed --
+            asm("" : "=v"(alb.xy), "=v"(alb.z));                // "defined" for the compiler without an instruction
             if (lane_in(fin)) {
                 const float tmin = bits_f32(bestk + kbias);
                 // What the shading step needs of the winner: its centre -- straight from the winner's own pair slot, no sphere index needed --
                 // and its index (light test, albedo), requested TOGETHER: one memory latency; the albedo (one more, it needs the index) is
                 // only used after the reflection.  (Round 3: index -> sphere8 record -> shading, two latencies in front of the arithmetic.)
                 const bool hit = bestk != kinit, by_pos = hit && !(bestp & kIdFlag);
-                float cx = 0.0f, cy = 0.0f, cz = 0.0f;
+                float cx, cy, cz;                               // set by exactly one of the two loads below (by_pos / !by_pos)
+                asm("" : "=v"(cx), "=v"(cy), "=v"(cz));
                 uint32_t id = bestp & ~kIdFlag;
                 if (by_pos) {
-                    const float *sg = reinterpret_cast<const float *>(slot_geom) + 8 * (size_t)(bestp >> 1) + (bestp & 1u);
-                    id = slot_ids[bestp];
+                    // (32-bit byte offsets from the scalar table bases: position p -> word 8 * (p >> 1) + (p & 1) = 4 * p - 3 * (p & 1))
+                    const float *sg = reinterpret_cast<const float *>(reinterpret_cast<const char *>(slot_geom) + ((bestp << 4) - 12u * (bestp & 1u)));
+                    id = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(slot_ids) + (bestp << 2));
                     cx = sg[0]; cy = sg[2]; cz = sg[4];
                     if (__builtin_expect(pend != kNoPos, 0)) {   // a recorded tie: the lower index wins (nearly always the same sphere again)
                         const uint32_t idp = slot_ids[pend];
@@ -811,12 +839,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SC == kScene
             apply_albedo(thr_xy, thr_z, alb, alive & fin);
             if (rr) roulette(fin);
             {   // park the finished paths of `fin` (park() of the 8-sphere form, restricted to these lanes)
-                uint64_t zero, at_depth, saved;
+                uint64_t zero, at_depth, saved, zero_unused;
                 uint32_t orbits;
                 asm("v_or3_b32 %0, %1, %2, %3" : "=v"(orbits) : "v"(thr_xy.x), "v"(thr_xy.y), "v"(thr_z));
                 asm("v_cmp_eq_f32_e64 %0, 0, %1" : "=s"(zero) : "v"(orbits));
                 at_depth = __builtin_amdgcn_ballot_w64(left == 0u);
-                if (lane_in(fin)) --left;
+                asm("v_subbrev_co_u32_e64 %0, %1, 0, %0, %2" : "+v"(left), "=s"(zero_unused) : "s"(fin));   // left -= 1 in the lanes of fin (0 - 0 - borrow)
                 const uint64_t done = fin & (((~alive | zero) & retire_mask) | at_depth);
                 asm volatile("s_and_saveexec_b64 %[sv], %[m]\n\t"
                              "ds_write_b32 %[ca], %[rx]\n\t"
@@ -861,6 +889,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SC == kScene
                     {
                         // the always-tested list: its first kBigLds pair slots from LDS (uniform addresses: broadcasts, all in flight together;
                         // pads are NaN spheres), the rest -- scenes with more than 2 * kBigLds large spheres -- by scalar loads
+                        // (Computing the four pairs' discriminants jointly in one basic block -- which saves the ten v_mov with which the compiler
+                        // materialises the ray's broadcast pairs across the blocks of the pair tests -- measured 40.08 against 40.17 ms at 64 spp and
+                        // cost 4 more spilled vector registers in the roulette instantiations: not kept.)
                         float4 big[2 * kBigLds];
 #pragma unroll
                         for (uint32_t j = 0; j < 2u * kBigLds; ++j) big[j] = tab[j];
