@@ -41,6 +41,7 @@ def test_single_process_dry_run_and_world_mismatch():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dry-run", "--steps", "2", "--warmup", "0"],
                        capture_output=True, text=True, timeout=300, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-1000:]
+    assert len([l for l in r.stdout.splitlines() if l.strip()]) == 1, r.stdout    # ONE line on stdout: nothing else (build output goes to stderr)
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
     assert out["n_gpus"] == 1 and out["scaling"] == "weak"
     # launched by something that set WORLD_SIZE to another value than --gpus: refused, not silently run with the wrong world
