@@ -620,6 +620,36 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SC == kScene
         const uint32_t nbig = h.slot_base;                      // pair slots of the always-tested list
         const float walk_margin = h.margin;
         __syncthreads();
+        // The generated scenes' always-tested list is the reference room: six walls (spheres 0..5 of the 8-sphere table, same order) and the
+        // light, i.e. the equality pattern of scene8_shares_planes() with the light in the pad's place of the fourth pair.  A wave that finds
+        // exactly that (bit for bit, on the LDS copy) replaces the copy by the eleven register pairs of intersect_pre_planes_pairs() -- the
+        // fourth pair as (pad, light), positions swapped back when the arg-min records a hit -- and computes the eight discriminants in 49
+        // instead of 64 packed instructions per segment start.
+        bool planes7 = false;
+        if (nbig == kBigLds) {
+            float4 g[2 * kBigLds];
+#pragma unroll
+            for (uint32_t j = 0; j < 2u * kBigLds; ++j) g[j] = tab[j];
+            auto eq = [](float a, float b) { return f32_bits(a) == f32_bits(b); };
+            const bool ok = eq(g[2].x, g[2].y) && eq(g[2].x, g[4].x) && eq(g[2].x, g[4].y) && eq(g[2].x, g[6].x) &&      // cx2 = cx3 = cx4 = cx5 = cx(light)
+                            eq(g[0].z, g[0].w) && eq(g[0].z, g[2].z) && eq(g[0].z, g[2].w) &&                            // cy0 = cy1 = cy2 = cy3
+                            eq(g[1].x, g[1].y) && eq(g[1].x, g[5].x) && eq(g[1].x, g[5].y) && eq(g[1].x, g[7].x) &&      // cz0 = cz1 = cz4 = cz5 = cz(light)
+                            g[6].y != g[6].y;                                                                              // position 7 is the pad
+            planes7 = __builtin_amdgcn_readfirstlane(ok ? 1 : 0) != 0;
+            if (planes7) {
+                __syncthreads();
+                if (lane == 0) {
+                    const float qn = __uint_as_float(0x7fc00000u);
+                    f2 *pp = reinterpret_cast<f2 *>(tab);
+                    pp[0] = f2{g[0].x, g[0].y}; pp[1] = f2{g[2].x, qn};       // X1 = (cx0, cx1)   X2 = (cx2, pad)
+                    pp[2] = f2{g[4].z, g[4].w}; pp[3] = f2{qn, g[6].z};       // Y1 = (cy4, cy5)   Y2 = (pad, cy light)
+                    pp[4] = f2{g[0].z, g[0].z};                               // Y3 = (cy0, cy0)
+                    pp[5] = f2{g[3].x, g[3].y}; pp[6] = f2{g[1].x, qn};       // Z1 = (cz2, cz3)   Z2 = (cz0, pad)
+                    pp[7] = f2{g[1].z, g[1].w}; pp[8] = f2{g[3].z, g[3].w}; pp[9] = f2{g[5].z, g[5].w}; pp[10] = f2{qn, g[7].z};   // r2 pairs, the last (pad, light)
+                }
+                __syncthreads();
+            }
+        }
         // root keys (pt_trace.h KeyConsts), wave-uniform here: scalar registers
         const uint32_t kbias = f32_bits(ta.eps) + 1u, kinit = f32_bits(kMissT) - kbias;
         const uint64_t nbias2 = ((uint64_t)(0u - kbias) << 32) | (0x80000000u - kbias);
@@ -645,9 +675,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SC == kScene
         // minimum, the second has the higher id of the two and cannot matter.)
         auto id_at = [&](uint32_t p) __attribute__((always_inline)) -> uint32_t { return (p & kIdFlag) ? (p & ~kIdFlag) : slot_ids[p]; };
         // `ties_tag` false: the list is the segment's first (the always-tested one), there is no earlier minimum to tie with.
-        auto test_pair = [&](const float4 a, const float4 c4, uint32_t pos, auto ties_tag) __attribute__((always_inline)) {
+        // `swap_tag`: the pair's halves stand in the OTHER order than their positions (planes form, fourth pair): first half = position pos + 1
+        auto test_post = [&](const HitPre2 hp, uint32_t pos, auto ties_tag, auto swap_tag) __attribute__((always_inline)) {
             constexpr bool TIES = decltype(ties_tag)::value;
-            const HitPre2 hp = intersect_pre2(a, c4, s.oxy.x, s.oxy.y, s.oz, s.dxy.x, s.dxy.y, s.dz);
+            constexpr bool SWAP = decltype(swap_tag)::value;
             const f2 r0 = {__builtin_amdgcn_rsqf(hp.disc.x), __builtin_amdgcn_rsqf(hp.disc.y)};   // sqrt_rn_rsq1 on both halves
             const f2 y = hp.disc * r0, hh = r0 * 0.5f;
             const f2 res = __builtin_elementwise_fma(-y, y, hp.disc);
@@ -665,7 +696,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SC == kScene
             // both candidates with the running minimum in turn: 4 more vector instructions per slot.)
             const bool isb = mb < ma;
             const uint32_t m2 = isb ? mb : ma;
-            const uint32_t psel = isb ? pos + 1u : pos;            // (a select of two inline constants in the always-tested list, an add-with-carry in the walk)
+            const uint32_t psel = SWAP ? (isb ? pos : pos + 1u) : (isb ? pos + 1u : pos);
             const bool take = m2 < bestk, tie = TIES && m2 == bestk;
             if (TIES && __builtin_expect(__builtin_amdgcn_ballot_w64(tie && pend != kNoPos) != 0, 0)) {
                 if (tie && pend != kNoPos) {
@@ -692,6 +723,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SC == kScene
             bestp = take_b ? pos + 1u : bestp;
             if (TIES) pend = (take_a || take_b) ? kNoPos : (tie ? pos + (eq_b ? 1u : 0u) : pend);
 #endif
+        };
+        auto test_pair = [&](const float4 a, const float4 c4, uint32_t pos, auto ties_tag) __attribute__((always_inline)) {
+            test_post(intersect_pre2(a, c4, s.oxy.x, s.oxy.y, s.oz, s.dxy.x, s.dxy.y, s.dz), pos, ties_tag, std::false_type{});
         };
         // cellslot[lin] -> the cell's POSITION range [cur, end) in the pair-slot tables
         auto fetch_range = [&]() __attribute__((always_inline)) {
@@ -892,14 +926,26 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SC == kScene
                         // (Computing the four pairs' discriminants jointly in one basic block -- which saves the ten v_mov with which the compiler
                         // materialises the ray's broadcast pairs across the blocks of the pair tests -- measured 40.08 against 40.17 ms at 64 spp and
                         // cost 4 more spilled vector registers in the roulette instantiations: not kept.)
-                        float4 big[2 * kBigLds];
+                        if (planes7) {                              // wave-uniform: the reference room (see above)
+                            const f2 *pp = reinterpret_cast<const f2 *>(tab);
+                            HitPre2 hp[4];
+                            intersect_pre_planes_pairs(pp[0], pp[1], pp[2], pp[3], pp[4], pp[5], pp[6], pp[7], pp[8], pp[9], pp[10],
+                                                       s.oxy.x, s.oxy.y, s.oz, s.dxy.x, s.dxy.y, s.dz, hp);
+                            test_post(hp[0], 0, std::false_type{}, std::false_type{});
+                            test_post(hp[1], 2, std::false_type{}, std::false_type{});
+                            test_post(hp[2], 4, std::false_type{}, std::false_type{});
+                            test_post(hp[3], 6, std::false_type{}, std::true_type{});    // (pad, light): the light is position 6
+                            if (STATS) n_tests += 8;
+                        } else {
+                            float4 big[2 * kBigLds];
 #pragma unroll
-                        for (uint32_t j = 0; j < 2u * kBigLds; ++j) big[j] = tab[j];
+                            for (uint32_t j = 0; j < 2u * kBigLds; ++j) big[j] = tab[j];
 #pragma unroll
-                        for (uint32_t j = 0; j < kBigLds; ++j) {
-                            if (j < nbig) {                         // wave-uniform
-                                test_pair(big[2 * j], big[2 * j + 1], 2 * j, std::false_type{});
-                                if (STATS) n_tests += 2;
+                            for (uint32_t j = 0; j < kBigLds; ++j) {
+                                if (j < nbig) {                         // wave-uniform
+                                    test_pair(big[2 * j], big[2 * j + 1], 2 * j, std::false_type{});
+                                    if (STATS) n_tests += 2;
+                                }
                             }
                         }
                         for (uint32_t j = kBigLds; j < nbig; ++j) {

@@ -111,11 +111,9 @@ __device__ __forceinline__ HitPre2 intersect_pre2(const float4 a, const float4 c
 // returns them.  Distinct coordinates in register pairs:  X1 = (cx0, cx1)  X2 = (cx2, cx6)   Y1 = (cy4, cy5)  Y2 = (cy6, cy7)
 // Y3 = (cy0, cy0)   Z1 = (cz2, cz3)  Z2 = (cz0, cz6); every sum of a sphere pair finds both of its operands inside ONE pair per
 // source (op_sel picks the halves), so nothing is shuffled.  Operation for operation what intersect_pre2 computes per sphere.
-__device__ __forceinline__ void intersect_pre_planes(const Scene8 &sc, float ox, float oy, float oz, float dx, float dy, float dz,
-                                                     HitPre2 (&h)[4]) {
-    const f2 X1 = {sc.cx[0], sc.cx[1]}, X2 = {sc.cx[2], sc.cx[6]};
-    const f2 Y1 = {sc.cy[4], sc.cy[5]}, Y2 = {sc.cy[6], sc.cy[7]}, Y3 = {sc.cy[0], sc.cy[0]};
-    const f2 Z1 = {sc.cz[2], sc.cz[3]}, Z2 = {sc.cz[0], sc.cz[6]};
+__device__ __forceinline__ void intersect_pre_planes_pairs(const f2 X1, const f2 X2, const f2 Y1, const f2 Y2, const f2 Y3, const f2 Z1, const f2 Z2,
+                                                           const f2 R0, const f2 R1, const f2 R2, const f2 R3, float ox, float oy, float oz,
+                                                           float dx, float dy, float dz, HitPre2 (&h)[4]) {
     const f2 x1 = X1 - ox, x2 = X2 - ox, y1 = Y1 - oy, y2 = Y2 - oy, y3 = Y3 - oy, z1 = Z1 - oz, z2 = Z2 - oz;
     auto lo = [](f2 v) { return f2{v.x, v.x}; };
     auto swap = [](f2 v) { return f2{v.y, v.x}; };
@@ -129,11 +127,16 @@ __device__ __forceinline__ void intersect_pre_planes(const Scene8 &sc, float ox,
     {   // c = ((ocx^2 + ocy^2) + ocz^2) - r2;  disc = b*b - c
         const f2 qx1 = x1 * x1, qx2 = x2 * x2, qy1 = y1 * y1, qy2 = y2 * y2, qy3 = y3 * y3, qz1 = z1 * z1, qz2 = z2 * z2;
         f2 c0 = (qx1 + qy3) + lo(qz2), c1 = (lo(qx2) + qy3) + qz1, c2 = (lo(qx2) + qy1) + lo(qz2), c3 = (swap(qx2) + qy2) + swap(qz2);
-        c0 = c0 - f2{sc.r2[0], sc.r2[1]}; c1 = c1 - f2{sc.r2[2], sc.r2[3]};
-        c2 = c2 - f2{sc.r2[4], sc.r2[5]}; c3 = c3 - f2{sc.r2[6], sc.r2[7]};
+        c0 = c0 - R0; c1 = c1 - R1; c2 = c2 - R2; c3 = c3 - R3;
         h[0].disc = h[0].b * h[0].b - c0; h[1].disc = h[1].b * h[1].b - c1;
         h[2].disc = h[2].b * h[2].b - c2; h[3].disc = h[3].b * h[3].b - c3;
     }
+}
+__device__ __forceinline__ void intersect_pre_planes(const Scene8 &sc, float ox, float oy, float oz, float dx, float dy, float dz,
+                                                     HitPre2 (&h)[4]) {
+    intersect_pre_planes_pairs(f2{sc.cx[0], sc.cx[1]}, f2{sc.cx[2], sc.cx[6]}, f2{sc.cy[4], sc.cy[5]}, f2{sc.cy[6], sc.cy[7]}, f2{sc.cy[0], sc.cy[0]},
+                               f2{sc.cz[2], sc.cz[3]}, f2{sc.cz[0], sc.cz[6]}, f2{sc.r2[0], sc.r2[1]}, f2{sc.r2[2], sc.r2[3]}, f2{sc.r2[4], sc.r2[5]},
+                               f2{sc.r2[6], sc.r2[7]}, ox, oy, oz, dx, dy, dz, h);
 }
 
 // ---- trace: reference scene (Ns == 8) ----------------------------------------------------
