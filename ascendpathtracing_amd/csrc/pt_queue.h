@@ -931,6 +931,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SC == kScene
                             HitPre2 hp[4];
                             intersect_pre_planes_pairs(pp[0], pp[1], pp[2], pp[3], pp[4], pp[5], pp[6], pp[7], pp[8], pp[9], pp[10],
                                                        s.oxy.x, s.oxy.y, s.oz, s.dxy.x, s.dxy.y, s.dz, hp);
+                            // (pinned: the compiler would sink parts of the joint arithmetic into the blocks of the four root tests and
+                            // materialise the broadcast operands with v_mov there)
+                            asm volatile("" : "+v"(hp[0].b), "+v"(hp[0].disc), "+v"(hp[1].b), "+v"(hp[1].disc), "+v"(hp[2].b), "+v"(hp[2].disc), "+v"(hp[3].b), "+v"(hp[3].disc));
                             test_post(hp[0], 0, std::false_type{}, std::false_type{});
                             test_post(hp[1], 2, std::false_type{}, std::false_type{});
                             test_post(hp[2], 4, std::false_type{}, std::false_type{});
