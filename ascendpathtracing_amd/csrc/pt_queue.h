@@ -29,6 +29,12 @@
 // to the full-trace kernel's and to the CPU restatement's, and the traced-segment count equals the oracle's.
 // A wave whose loop bound trips (a logic error; never seen) or whose LDS does not start at address 0 says so through the context's
 // device status word (include/render_mi355x.h APT_DEV_*; the reference asserts inside its kernel, src/render.cpp:68-73).
+//
+// How the hot code is written (round 4): these kernels run at the issue rate of the vector pipe, so what they cost is their instruction
+// COUNT.  Which lanes do what is kept in WAVE MASKS on the scalar unit; a per-lane `bool` made from a mask (v_cndmask + v_cmp) or a mask
+// made from a bool set inside a divergent region costs two vector instructions each way, so the hot paths branch on the masks themselves
+// (wave-uniform), compute unmasked -- an instruction costs its issue slot whatever the execution mask -- and write per-lane state through
+// selects on the masks or short exec-masked asm groups (park / refill, roulette(), the grid form's turn()).
 #pragma once
 #include <type_traits>
 
@@ -427,65 +433,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SC == kScene
     // reach an output left the validity range of the fast sequences (about 1e-5 of the wave-bounces) is known BEFORE the new ray
     // is written, so the exact form (sqrtf() and '/', a cold block) still finds the old ray in the state registers and the fast form
     // writes the new ray over them (fewer live registers and copies: C2 with retirement 16.69 -> 16.33 ms, depth 32 35.2 -> 34.4).
-#ifdef APT_QUEUE_JOIN_LOOP
-    auto step = [&](PathState &st, auto planes_tag) __attribute__((always_inline)) {
-        constexpr bool PLANES = decltype(planes_tag)::value;
-        // (Only used by the measurement form of run() below, -DAPT_QUEUE_JOIN_LOOP; with roulette it keeps the one-block bounce, which that
-        // form ran faster: 15.35 against 15.45 ms.)
-        if (RR) {
-            PathState nx;
-            Albedo albedo;
-            uint64_t alive_out = alive;
-            bool redo_any = !fast_ok;
-            if (__builtin_expect(fast_ok, 1)) {
-                const uint64_t redo = bounce_ns8_v2<MODE, PLANES>(sc, tab8, st, nx, ta, kc, alive_out, albedo) & active;
-                if (__builtin_expect(redo != 0, 0)) { // a finished path's request is ignored (trace_ns8)
-                    const bool fin = select_const(alive, 1) == 0 || (thr_xy.x == 0.0f && thr_xy.y == 0.0f && thr_z == 0.0f);
-                    redo_any = __builtin_amdgcn_ballot_w64(select_const(redo, 1) != 0 && !fin) != 0; // (ballot: uniform for the compiler, __any is not)
-                }
-            }
-            if (__builtin_expect(redo_any, 0)) {
-                ++n_exact;
-                PathState c = st, o;
-                c.rxy = thr_xy; c.rz = thr_z; c.alive = select_const(alive, 1);
-                (void)bounce_ns8<MODE, false>(sc, tab8, c, o, ta);
-                nx.oxy = o.oxy; nx.oz = o.oz; nx.dxy = o.dxy; nx.dz = o.dz;
-                thr_xy = o.rxy; thr_z = o.rz;
-                alive = __builtin_amdgcn_ballot_w64(o.alive != 0);
-            } else {
-                apply_albedo(thr_xy, thr_z, albedo, alive_out);
-                alive = alive_out;
-            }
-            st.oxy = nx.oxy; st.oz = nx.oz; st.dxy = nx.dxy; st.dz = nx.dz;
-        } else {
-            Bounce8Mid mid;
-            bool redo_any = !fast_ok;
-            if (__builtin_expect(fast_ok, 1)) {
-                const uint64_t redo = bounce_ns8_v2_hit<MODE, PLANES>(sc, tab8, st, ta, kc, mid) & active;
-                if (__builtin_expect(redo != 0, 0)) { // a finished path's request is ignored (trace_ns8)
-                    const bool fin = select_const(alive, 1) == 0 || (thr_xy.x == 0.0f && thr_xy.y == 0.0f && thr_z == 0.0f);
-                    redo_any = __builtin_amdgcn_ballot_w64(select_const(redo, 1) != 0 && !fin) != 0; // (ballot: uniform for the compiler, __any is not)
-                }
-            }
-            if (__builtin_expect(redo_any, 0)) {
-                ++n_exact;
-                PathState c = st, o;
-                c.rxy = thr_xy; c.rz = thr_z; c.alive = select_const(alive, 1);
-                (void)bounce_ns8<MODE, false>(sc, tab8, c, o, ta);
-                st.oxy = o.oxy; st.oz = o.oz; st.dxy = o.dxy; st.dz = o.dz;
-                thr_xy = o.rxy; thr_z = o.rz;
-                alive = __builtin_amdgcn_ballot_w64(o.alive != 0);
-            } else {
-                Albedo albedo;
-                uint64_t alive_out = alive;
-                bounce_ns8_v2_reflect<MODE>(st, mid, alive_out, albedo);
-                apply_albedo(thr_xy, thr_z, albedo, alive_out);
-                alive = alive_out;
-            }
-        }
-        post_bounce();
-    };
-#endif
 
     // Service between two bounces: park, refill from what the pool holds; when the pool has room for a batch, (sum the oldest
     // unit if its buffer is needed,) generate 64 rays and refill again, so that a lane never idles because the pool ran dry.
@@ -515,7 +462,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SC == kScene
     // retirement 16.1 -> 17.7 ms, C4 180 -> 204).
     constexpr uint32_t kGuardTripped = 0xffffffffu;
     auto run = [&](auto planes_tag) __attribute__((always_inline)) {
-#ifndef APT_QUEUE_JOIN_LOOP
         {
             // The hot loop holds the FAST form only and leaves through an exit taken before anything of the new ray is written (phase 1
             // of the bounce decides): no join of a fast and an exact arm inside the loop, so the register allocator keeps the new ray in
@@ -555,12 +501,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SC == kScene
                 }
             }
         }
-#else   // (measurement: fast and exact arm of the bounce joined inside one loop, step() above)
-        for (;;) {
-            if (service(s) || guard-- == 0u) break;
-            step(s, planes_tag);
-        }
-#endif
     };
     // ---- SC == kSceneGrid: any scene through the grid's pair-slot tables, every lane at its own place of its own walk -----------
     // Why this form.  The nested walk of render_frame_kernel (pt_trace.h grid_segment) is bound by the CU's vector-memory ADDRESS
@@ -690,7 +630,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SC == kScene
             }
             const uint64_t ka = root_pair<0>(hp.b, q) + nbias2, kb = root_pair<1>(hp.b, q) + nbias2;   // intersect_ns8_v2's keys
             const uint32_t ma = min((uint32_t)ka, (uint32_t)(ka >> 32)), mb = min((uint32_t)kb, (uint32_t)(kb >> 32));
-#ifndef APT_GRID_OLD_TIES
             // The slot's own winner first (equal keys inside a slot: the first candidate, it has the lower id), then ONE comparison with the
             // running minimum: nearer -> take it (and void a recorded tie), equal -> record the tie, farther -> nothing.  (Round 3 compared
             // both candidates with the running minimum in turn: 4 more vector instructions per slot.)
@@ -707,22 +646,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SC == kScene
             bestp = take ? psel : bestp;
             if (TIES) pend = take ? kNoPos : (tie ? psel : pend);
             bestk = min(bestk, m2);                             // (last: the compares above read the old minimum)
-#else
-            const bool eq_a = TIES && ma == bestk, eq_b = TIES && mb == bestk && !eq_a, tie = eq_a || eq_b;
-            if (TIES && __builtin_expect(__builtin_amdgcn_ballot_w64(tie && pend != kNoPos) != 0, 0)) {
-                if (tie && pend != kNoPos) {
-                    if (slot_ids[pend] < id_at(bestp)) bestp = pend;
-                    pend = kNoPos;
-                }
-            }
-            const bool take_a = ma < bestk;
-            bestk = take_a ? ma : bestk;
-            bestp = take_a ? pos : bestp;
-            const bool take_b = mb < bestk;
-            bestk = take_b ? mb : bestk;
-            bestp = take_b ? pos + 1u : bestp;
-            if (TIES) pend = (take_a || take_b) ? kNoPos : (tie ? pos + (eq_b ? 1u : 0u) : pend);
-#endif
         };
         auto test_pair = [&](const float4 a, const float4 c4, uint32_t pos, auto ties_tag) __attribute__((always_inline)) {
             test_post(intersect_pre2(a, c4, s.oxy.x, s.oxy.y, s.oz, s.dxy.x, s.dxy.y, s.dz), pos, ties_tag, std::false_type{});
