@@ -664,6 +664,22 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SC == kScene
         // halves are wave-uniform and the per-lane updates are selects on those masks or exec-masked instructions.  (The first form put the
         // halves in divergent `if`s: every mask -> bool -> mask round trip is a v_cndmask + v_cmp pair, five of them per turn.)
         auto turn = [&]() __attribute__((always_inline)) {
+            // FIRST the test of one pair slot for the lanes that have one, THEN the cell step for the lanes whose list is exhausted -- those of
+            // empty cells and those that have just tested their last slot: the walk's last step (the one that finds "nothing nearer can lie
+            // ahead") shares a turn with the last test instead of costing one of its own.  (Rounds 3-4 ran the halves in the other order: a
+            // lane stepping into a non-empty cell tested its first slot in the same turn, and every walk ended with a turn that only stepped:
+            // one turn more per segment whenever the first cell is not empty.)
+            const uint64_t has = walking & __builtin_amdgcn_ballot_w64(cur < end);
+            if (has != 0) {
+                if (lane_in(has)) {
+                    // slot cur / 2: float4s 2 * slot and 2 * slot + 1, by a 32-bit byte offset from the table's (scalar) base (positions have 27 bits)
+                    const float4 *sg = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(slot_geom) + (cur << 4));
+                    const float4 a = sg[0], c4 = sg[1];
+                    test_pair(a, c4, cur, std::true_type{});
+                    cur += 2u;
+                    if (STATS) n_tests += 2;
+                }
+            }
             const uint64_t need = walking & __builtin_amdgcn_ballot_w64(cur >= end);     // list exhausted: leave the cell
             uint64_t stopm = 0;
             if (need != 0) {
@@ -717,17 +733,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SC == kScene
                 }
                 if (STATS) n_cells += select_const(go, 1);
                 walking &= ~stopm;
-            }
-            const uint64_t has = walking & __builtin_amdgcn_ballot_w64(cur < end);
-            if (has != 0) {
-                if (lane_in(has)) {
-                    // slot cur / 2: float4s 2 * slot and 2 * slot + 1, by a 32-bit byte offset from the table's (scalar) base (positions have 27 bits)
-                    const float4 *sg = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(slot_geom) + (cur << 4));
-                    const float4 a = sg[0], c4 = sg[1];
-                    test_pair(a, c4, cur, std::true_type{});
-                    cur += 2u;
-                    if (STATS) n_tests += 2;
-                }
             }
         };
         // ---- the per-segment block for the lanes of `batch` (none of them walking): finish the segment they hold, park / refill,
