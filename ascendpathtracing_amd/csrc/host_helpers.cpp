@@ -334,7 +334,7 @@ int apt_build_grid_host(const float *sph, uint32_t ns, void *grid, size_t *out_b
     float *ig = (float *)(w + h.off_item_geom);
     for (uint32_t i = 0; i < h.nitems; ++i) memcpy(ig + 4 * (size_t)i, g + 4 * (size_t)w[h.off_items + i], 16);
     if (h.off_cellslot) {                                                                             // pair-slot tables of the flat walk
-        for (uint32_t c = 0; c <= h.ncells; ++c) apt::grid_fill_cell_slots(w, h, c);
+        for (uint32_t t = 0, nb = apt::grid_bordered_cells(h.n); t <= nb; ++t) apt::grid_fill_cell_slots(w, h, t);
         for (uint32_t k = 0; k < ns; ++k) apt::grid_fill_sphere8(w, h, sph, k);
     }
     return APT_OK;

@@ -625,7 +625,7 @@ APT_HD void path_uniforms(uint64_t seed, uint64_t path, double &u1, double &u2) 
 //   GridHeader | large[nlarge] | cell_start[ncells+1] | items[nitems] | geom[Ns] float4 (cx,cy,cz,r2)
 //              | item_geom[nitems] float4 = geom[items[i]]  (cell order: the walk reads it directly, one
 //                dependent load fewer per candidate)
-//              | cellslot[ncells] | slot_geom[nslots] (8 words) | slot_ids[nslots] (2 words)  -- the PAIR-SLOT tables of the flat walk
+//              | cellslot[(n0+2)(n1+2)(n2+2)] | slot_geom[nslots] (8 words) | slot_ids[nslots] (2 words)  -- the PAIR-SLOT tables of the flat walk
 //              | sphere8[Ns] (8 words)
 // Pair slots (round 3; pt_trace.h grid_segment_flat): the candidates of a list, two per slot, laid out for the packed
 // two-spheres-per-instruction test and for ONE address per pair:
@@ -633,7 +633,10 @@ APT_HD void path_uniforms(uint64_t seed, uint64_t path, double &u1, double &u2) 
 // Slots [0, slot_base) hold the always-tested large list, then every cell's list from slot
 //   grid_slot_begin(h, cell_start[c], c) = slot_base + ((cell_start[c] + c + 1) >> 1)
 // (lists of ceil(k / 2) slots never overlap under this rule -- no second scan; the few gap slots stay zero and are never read).
-// cellslot[c] = slot_begin << 6 | min(slots of the cell, 63); 63 means "63 or more: take the count from cell_start".
+// cellslot is indexed by BORDERED cell coordinates, ((z + 1) * (n1 + 2) + (y + 1)) * (n0 + 2) + (x + 1): one layer of cells around the grid holds
+// kGridCellOutside, so that a walk that leaves the box reads "outside" where it reads the next cell's range and keeps no count of the steps it has
+// left (round 4: six vector instructions per loop turn of the walk).  An inner entry = slot_begin << 6 | slots of the cell, or | 63 for "62 or more:
+// take the count from cell_start" (62 in the count field is the outside mark).
 // off_cellslot == 0: the tables are absent (they would not fit 26 bits of slot index) and the walk uses item_geom.
 struct GridHeader {
     uint32_t magic, num_spheres;
@@ -647,6 +650,8 @@ struct GridHeader {
 };
 constexpr uint32_t kGridSlotCountBits = 6;       // cellslot: low bits = slots of the cell, saturating
 constexpr uint32_t kGridSlotCountMax = (1u << kGridSlotCountBits) - 1u;
+constexpr uint32_t kGridCellOutside = kGridSlotCountMax - 1u;   // cellslot entry of the border layer (count field 62, slot 0)
+APT_HD uint32_t grid_bordered_cells(const uint32_t n[3]) { return (n[0] + 2u) * (n[1] + 2u) * (n[2] + 2u); }
 constexpr uint32_t kGridNoSphere = 0xffffffffu;  // id of a pad
 constexpr uint32_t kGridMagic = 0x47524944u; // "GRID"
 constexpr double kGridSpheresPerCell = 0.5;     // default cell size of both builders: sphere centres per cell (APT_GRID_SPHERES_PER_CELL overrides)
@@ -688,7 +693,7 @@ inline size_t grid_header_offsets(GridHeader &h, uint32_t nitems) { // -> total 
     // pair-slot tables: capacity from the placement rule (grid_slot_begin): the last list ends at or before this slot
     h.slot_base = (h.nlarge + 1u) >> 1;
     const uint64_t nslots = (uint64_t)h.slot_base + (((uint64_t)nitems + h.ncells + 1u) >> 1) + 1u;
-    const uint64_t off_cellslot = words, off_slots = (off_cellslot + h.ncells + 7u) & ~(uint64_t)7u;   // 32-byte aligned slots
+    const uint64_t off_cellslot = words, off_slots = (off_cellslot + grid_bordered_cells(h.n) + 7u) & ~(uint64_t)7u;   // 32-byte aligned slots
     const uint64_t off_ids = off_slots + nslots * 8u, off_s8 = (off_ids + nslots * 2u + 7u) & ~(uint64_t)7u, end = off_s8 + 8ull * h.num_spheres;
     if (nslots < (1ull << (32 - kGridSlotCountBits)) && end < (1ull << 32)) {
         h.off_cellslot = (uint32_t)off_cellslot; h.off_slots = (uint32_t)off_slots; h.off_slot_ids = (uint32_t)off_ids; h.nslots = (uint32_t)nslots;
@@ -702,7 +707,7 @@ inline size_t grid_header_offsets(GridHeader &h, uint32_t nitems) { // -> total 
 APT_HD uint32_t grid_slot_begin(const GridHeader &h, uint32_t cell_start_c, uint32_t c) { return h.slot_base + ((cell_start_c + c + 1u) >> 1); }
 APT_HD uint32_t grid_cellslot_entry(const GridHeader &h, uint32_t b, uint32_t e, uint32_t c) {
     const uint32_t n = (e - b + 1u) >> 1;
-    return grid_slot_begin(h, b, c) << kGridSlotCountBits | (n < kGridSlotCountMax ? n : kGridSlotCountMax);
+    return grid_slot_begin(h, b, c) << kGridSlotCountBits | (n < kGridCellOutside ? n : kGridSlotCountMax);
 }
 // The slots of one sorted id list (n ids from `ids`), starting at slot `slot`; geometry from the geom[] table already in the buffer.
 APT_HD void grid_fill_slots(uint32_t *w, const GridHeader &h, uint32_t slot, const uint32_t *ids, uint32_t n) {
@@ -723,11 +728,16 @@ APT_HD void grid_fill_sphere8(uint32_t *w, const GridHeader &h, const float *sph
     r[0] = sph[ns + k]; r[1] = sph[2 * ns + k]; r[2] = sph[3 * ns + k]; r[3] = sph[k];
     r[4] = sph[7 * ns + k]; r[5] = sph[8 * ns + k]; r[6] = sph[9 * ns + k]; r[7] = 0.0f;
 }
-// cellslot entry and slots of cell c (c == ncells: the always-tested list); needs cell_start, items, large and geom in place
-APT_HD void grid_fill_cell_slots(uint32_t *w, const GridHeader &h, uint32_t c) {
-    if (c == h.ncells) { grid_fill_slots(w, h, 0, w + h.off_large, h.nlarge); return; }
+// cellslot entry t of the BORDERED table and the slots of its cell (t == grid_bordered_cells: the always-tested list); needs cell_start, items,
+// large and geom in place
+APT_HD void grid_fill_cell_slots(uint32_t *w, const GridHeader &h, uint32_t t) {
+    if (t == grid_bordered_cells(h.n)) { grid_fill_slots(w, h, 0, w + h.off_large, h.nlarge); return; }
+    const uint32_t sx = h.n[0] + 2u, sy = h.n[1] + 2u;
+    const uint32_t xb = t % sx, yb = (t / sx) % sy, zb = t / (sx * sy);
+    if (xb == 0 || yb == 0 || zb == 0 || xb == h.n[0] + 1u || yb == h.n[1] + 1u || zb == h.n[2] + 1u) { w[h.off_cellslot + t] = kGridCellOutside; return; }
+    const uint32_t c = ((zb - 1u) * h.n[1] + (yb - 1u)) * h.n[0] + (xb - 1u);
     const uint32_t b = w[h.off_cells + c], e = w[h.off_cells + c + 1];
-    w[h.off_cellslot + c] = grid_cellslot_entry(h, b, e, c);
+    w[h.off_cellslot + t] = grid_cellslot_entry(h, b, e, c);
     grid_fill_slots(w, h, grid_slot_begin(h, b, c), w + h.off_items + b, e - b);
 }
 // cells [c0, c1] of axis a that the box of a small sphere (centre c, radius rad), inflated by the margin, touches

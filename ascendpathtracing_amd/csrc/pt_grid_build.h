@@ -216,10 +216,10 @@ __global__ __launch_bounds__(256) void grid_geom_kernel(const float *__restrict_
     if (i < nitems) { const uint32_t k = items[i]; item_geom[i] = make_float4(sph[ns + k], sph[2 * (size_t)ns + k], sph[3 * (size_t)ns + k], sph[k]); }
 }
 
-// pair-slot tables (pt_core.h): one thread per cell, thread ncells the always-tested list; after grid_geom_kernel
+// pair-slot tables (pt_core.h): one thread per entry of the bordered cellslot table, one more for the always-tested list; after grid_geom_kernel
 __global__ __launch_bounds__(256) void grid_slots_kernel(uint32_t *__restrict__ w, GridHeader h, const float *__restrict__ sph) {
     const uint32_t c = blockIdx.x * 256 + threadIdx.x;
-    if (c <= h.ncells) grid_fill_cell_slots(w, h, c);
+    if (c <= grid_bordered_cells(h.n)) grid_fill_cell_slots(w, h, c);
     if (c < h.num_spheres) grid_fill_sphere8(w, h, sph, c);
 }
 

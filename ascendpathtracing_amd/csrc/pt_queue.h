@@ -601,10 +601,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SC == kScene
         uint32_t pend = kNoPos;                                 // position of a candidate that tied with the running minimum (see test_pair)
         float tm0 = 0.f, tm1 = 0.f, tm2 = 0.f, td0 = 0.f, td1 = 0.f, td2 = 0.f;
         int inc0 = 0, inc1 = 0, inc2 = 0;                       // linear cell index increment per axis step
-        uint32_t lin = 0, rem = 0, cur = 0, end = 0;            // cell, steps left per axis (9 bits + guard bit each), POSITION cursor / end (2 per slot)
+        uint32_t lin = 0, cur = 0, end = 0;                     // cell (index into the BORDERED cellslot table), POSITION cursor / end (2 per slot)
         uint32_t n_cells = 0, n_tests = 0;                      // statistics
         uint64_t walking = 0, has_seg = 0;                      // lanes in a walk / lanes whose registers hold a (finished or running) segment
-        constexpr uint32_t kGuard = (1u << 9) | (1u << 19) | (1u << 29);
         auto lane_in = [&](uint64_t m) __attribute__((always_inline)) -> bool { return select_const(m, 1) != 0; };
         // Two candidates (a pair slot) against the lane's ray; `pos` = position of the first.  Equal keys mean equal t: the lower SPHERE
         // index must win (the reference's strict '<' over ascending indices).  Inside a slot and inside a list the ids ascend, so an
@@ -651,11 +650,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SC == kScene
             test_post(intersect_pre2(a, c4, s.oxy.x, s.oxy.y, s.oz, s.dxy.x, s.dxy.y, s.dz), pos, ties_tag, std::false_type{});
         };
         // cellslot[lin] -> the cell's POSITION range [cur, end) in the pair-slot tables
+        // a long list's slot count from cell_start (rare: clustered scenes); `lb`: bordered cell index -> the grid's own linear cell index
+        auto long_count = [&](uint32_t lb) __attribute__((always_inline)) -> uint32_t {
+            const uint32_t n0 = __float_as_uint(hl[1].w), n1 = __float_as_uint(hl[2].w), sx = n0 + 2u, sy = n1 + 2u;
+            const uint32_t xb = lb % sx, yb = (lb / sx) % sy, zb = lb / (sx * sy);
+            const uint32_t c = ((zb - 1u) * n1 + (yb - 1u)) * n0 + (xb - 1u);
+            return (cell_start[c + 1] - cell_start[c] + 1u) >> 1;
+        };
         auto fetch_range = [&]() __attribute__((always_inline)) {
             const uint32_t cs = cellslot[lin];
             cur = (cs >> kGridSlotCountBits) << 1;
             uint32_t cnt = cs & kGridSlotCountMax;
-            if (cnt == kGridSlotCountMax) cnt = (cell_start[lin + 1] - cell_start[lin] + 1u) >> 1;   // a long list (clustered scenes)
+            if (cnt == kGridSlotCountMax) cnt = long_count(lin);   // a long list (clustered scenes)
             end = cur + 2u * cnt;
             if (STATS) ++n_cells;
         };
@@ -693,24 +699,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SC == kScene
                 asm("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(tm0) : "v"(a0), "s"(m0));
                 asm("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(tm1) : "v"(a1), "s"(m1));
                 asm("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(tm2) : "v"(a2), "s"(m2));
-                // lin += axis 0 ? inc0 : (axis 1 ? inc1 : inc2); steps left: one less in the axis' 10-bit field (shift 0 / 10 / 20: inline constants)
-                uint32_t sel, sh;
+                // lin += axis 0 ? inc0 : (axis 1 ? inc1 : inc2), in the bordered table: a step out of the grid lands on an "outside" entry (no count
+                // of the steps left: round 3 kept three 10-bit counters in a register, six vector instructions per turn)
+                uint32_t sel;
                 asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(sel) : "v"(inc2), "v"(inc1), "s"(m1));
                 asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(sel) : "v"(sel), "v"(inc0), "s"(m0));
-                asm("v_cndmask_b32_e64 %0, 20, 10, %1" : "=v"(sh) : "s"(m1));
-                asm("v_cndmask_b32_e64 %0, %1, 0, %2" : "=v"(sh) : "v"(sh), "s"(m0));
-                const uint32_t dec = 1u << sh;
                 uint64_t saved;
                 asm volatile("s_and_saveexec_b64 %[sv], %[m]\n\t"
                              "v_add_u32 %[lin], %[lin], %[sel]\n\t"
-                             "v_sub_u32 %[rem], %[rem], %[dec]\n\t"
                              "s_mov_b64 exec, %[sv]"
-                             : [sv] "=&s"(saved), [lin] "+v"(lin), [rem] "+v"(rem)
-                             : [m] "s"(need), [sel] "v"(sel), [dec] "v"(dec)
+                             : [sv] "=&s"(saved), [lin] "+v"(lin)
+                             : [m] "s"(need), [sel] "v"(sel)
                              : "scc");
-                // nothing nearer can lie ahead, or the next cell is outside the grid (an axis with no steps left lost its guard bit)
-                stopm = need & (__builtin_amdgcn_ballot_w64(tmin < te - (1e-3f * fabsf(te) + walk_margin)) |
-                                __builtin_amdgcn_ballot_w64((rem & kGuard) != kGuard));
+                // nothing nearer can lie ahead
+                stopm = need & __builtin_amdgcn_ballot_w64(tmin < te - (1e-3f * fabsf(te) + walk_margin));
                 const uint64_t go = need & ~stopm;
                 // cellslot[lin] -> the next cell's POSITION range (fetch_range()), for the lanes of `go`; the value is needed at once
                 uint32_t cnt;
@@ -727,11 +729,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SC == kScene
                              : [m] "s"(go), [lin] "v"(lin), [base] "s"(cellslot)
                              : "scc", "memory");
                 static_assert(kGridSlotCountBits == 6 && kGridSlotCountMax == 63, "the shifts and masks of the block above");
-                const uint64_t longl = go & __builtin_amdgcn_ballot_w64(cnt == kGridSlotCountMax);
-                if (__builtin_expect(longl != 0, 0)) {           // a long list (clustered scenes): the count from cell_start
-                    if (lane_in(longl)) end = cur + 2u * ((cell_start[lin + 1] - cell_start[lin] + 1u) >> 1);
+                // ... or the step has left the grid: the border layer's entry (the count field's two top values: "outside" and "long list")
+                const uint64_t special = go & __builtin_amdgcn_ballot_w64(cnt >= kGridCellOutside);
+                if (special != 0) {
+                    const uint64_t outside = special & __builtin_amdgcn_ballot_w64(cnt == kGridCellOutside), longl = special & ~outside;
+                    stopm |= outside;
+                    if (__builtin_expect(longl != 0, 0)) {       // a long list (clustered scenes): the count from cell_start
+                        if (lane_in(longl)) end = cur + 2u * long_count(lin);
+                    }
                 }
-                if (STATS) n_cells += select_const(go, 1);
+                if (STATS) n_cells += select_const(go & ~stopm, 1);
                 walking &= ~stopm;
             }
         };
@@ -932,23 +939,21 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SC == kScene
                     if (go) {
                         // per axis: the parameter of the boundary ahead -- plane ci + 1 (dv > 0) or ci (dv < 0) of the axis, relative to the
                         // box corner like e --, the parameter step per cell (-cellw * inv = cellw * |inv| for dv < 0), the linear-index step
-                        // and the steps left.  An axis the ray does not move along gets a crossing that never comes first (it is never the
+                        // in the bordered cellslot table.  An axis the ray does not move along gets a crossing that never comes first (it is never the
                         // nearest crossing of a unit direction within kMissT), so its other values are never used.
-                        auto axis = [&](float e, float dv, float inv, float cellw, int ci, int na, int stride, int &inc, uint32_t &steps, float &tmax,
+                        auto axis = [&](float e, float dv, float inv, float cellw, int ci, int stride, int &inc, float &tmax,
                                         float &tdel) __attribute__((always_inline)) {
                             const bool fwd = dv > 0.0f, moves = fabsf(dv) > 1e-20f;
                             const float t_b = __builtin_fmaf((float)(ci + (fwd ? 1 : 0)), cellw, -e) * inv;
                             tmax = moves ? t_b : 3.0e38f;
                             tdel = moves ? cellw * fabsf(inv) : 3.0e38f;
                             inc = fwd ? stride : -stride;
-                            steps = (uint32_t)(fwd ? na - 1 - ci : ci);
                         };
-                        uint32_t l0, l1, l2;
-                        axis(e0, s.dxy.x, ix, hc.x, c0, n0, 1, inc0, l0, tm0, td0);
-                        axis(e1, s.dxy.y, iy, hc.y, c1, n1, n0, inc1, l1, tm1, td1);
-                        axis(e2, s.dz, iz, hc.z, c2, n2, n0 * n1, inc2, l2, tm2, td2);
-                        lin = (uint32_t)((c2 * n1 + c1) * n0 + c0);
-                        rem = kGuard | l0 | l1 << 10 | l2 << 20;
+                        const int sx = n0 + 2, sy = n1 + 2;         // strides of the bordered table
+                        axis(e0, s.dxy.x, ix, hc.x, c0, 1, inc0, tm0, td0);
+                        axis(e1, s.dxy.y, iy, hc.y, c1, sx, inc1, tm1, td1);
+                        axis(e2, s.dz, iz, hc.z, c2, sx * sy, inc2, tm2, td2);
+                        lin = (uint32_t)(((c2 + 1) * sy + (c1 + 1)) * sx + (c0 + 1));
                         // (Requesting this first range before the axis arithmetic and waiting after it -- inline-asm load -- was measured:
                         // 52.5 against 44.7 ms at 64 spp; the asm's memory clobber doubled the spilled scalar registers.)
                         fetch_range();

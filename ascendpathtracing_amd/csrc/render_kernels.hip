@@ -650,7 +650,7 @@ int apt_build_grid_device(const float *spheres_dev, uint32_t ns, void *stream, v
                     const uint32_t ng = ns > nitems ? ns : nitems;
                     if (!break_out) hipLaunchKernelGGL(grid_geom_kernel, dim3((ng + 255) / 256), dim3(256), 0, st, spheres_dev, ns, w + h.off_items, nitems,
                                        reinterpret_cast<float4 *>(w + h.off_geom), reinterpret_cast<float4 *>(w + h.off_item_geom));
-                    if (!break_out && h.off_cellslot) hipLaunchKernelGGL(grid_slots_kernel, dim3((std::max(h.ncells + 1u, ns) + 255u) / 256u), dim3(256), 0, st, w, h, spheres_dev);
+                    if (!break_out && h.off_cellslot) hipLaunchKernelGGL(grid_slots_kernel, dim3((std::max(apt::grid_bordered_cells(h.n) + 1u, ns) + 255u) / 256u), dim3(256), 0, st, w, h, spheres_dev);
                     if (e == hipSuccess) e = hipGetLastError();
                     if (e == hipSuccess) e = hipStreamSynchronize(st);       // the workspace is freed below
                 }

@@ -62,10 +62,19 @@ static void check_grid(const char *name, std::vector<float> &scene, uint32_t ns)
         const uint32_t *cellslot = w.data() + h.off_cellslot, *ids = w.data() + h.off_slot_ids;
         const float *sg = (const float *)(w.data() + h.off_slots);
         CHECK((size_t)h.off_sphere8 + 8 * (size_t)ns == bytes / 4, "%s: table end", name);
+        // cellslot is indexed by bordered cell coordinates (round 4): the layer around the grid holds the "outside" mark
+        const uint32_t sx = h.n[0] + 2, sy = h.n[1] + 2, sz = h.n[2] + 2;
+        CHECK((size_t)h.off_cellslot + apt::grid_bordered_cells(h.n) <= h.off_slots, "%s: bordered cellslot table overlaps the slots", name);
+        for (uint32_t t = 0; t < sx * sy * sz; ++t) {
+            const uint32_t xb = t % sx, yb = (t / sx) % sy, zb = t / (sx * sy);
+            if (xb == 0 || yb == 0 || zb == 0 || xb == sx - 1 || yb == sy - 1 || zb == sz - 1) CHECK(cellslot[t] == apt::kGridCellOutside, "%s: border entry %u", name, t);
+        }
         for (uint32_t c = 0; c < h.ncells; ++c) {
             const uint32_t b = cells[c], e = cells[c + 1], n = (e - b + 1) >> 1;
-            const uint32_t slot0 = cellslot[c] >> apt::kGridSlotCountBits, cnt = cellslot[c] & apt::kGridSlotCountMax;
-            CHECK(slot0 == apt::grid_slot_begin(h, b, c) && cnt == (n < apt::kGridSlotCountMax ? n : apt::kGridSlotCountMax), "%s: cellslot[%u]", name, c);
+            const uint32_t x = c % h.n[0], y = (c / h.n[0]) % h.n[1], z = c / (h.n[0] * h.n[1]);
+            const uint32_t entry = cellslot[((z + 1) * sy + (y + 1)) * sx + (x + 1)];
+            const uint32_t slot0 = entry >> apt::kGridSlotCountBits, cnt = entry & apt::kGridSlotCountMax;
+            CHECK(slot0 == apt::grid_slot_begin(h, b, c) && cnt == (n < apt::kGridCellOutside ? n : apt::kGridSlotCountMax), "%s: cellslot of cell %u", name, c);
             CHECK((uint64_t)slot0 + n <= h.nslots, "%s: slots of cell %u beyond the table", name, c);
             for (uint32_t i = b; i < e; ++i) {                 // candidate i - b sits in slot slot0 + (i-b)/2, half (i-b)&1
                 const uint32_t s = slot0 + ((i - b) >> 1), half = (i - b) & 1u;

@@ -198,11 +198,19 @@ def test_grid_builder_layout(apt):
     check_list(0, g[off_large:off_large + nlarge].tolist())
     used = np.zeros(nslots, dtype=bool)
     used[:slot_base] = True
+    # round 4: cellslot is indexed by BORDERED cell coordinates; the layer around the grid holds the "outside" mark (count field 62, slot 0)
+    n0, n1, n2 = (int(x) for x in n)
+    cs = g[off_cellslot:off_cellslot + (n0 + 2) * (n1 + 2) * (n2 + 2)].reshape(n2 + 2, n1 + 2, n0 + 2)
+    border = np.ones(cs.shape, dtype=bool)
+    border[1:-1, 1:-1, 1:-1] = False
+    assert (cs[border] == 62).all() and off_slots >= off_cellslot + cs.size
+    inner = cs[1:-1, 1:-1, 1:-1].reshape(-1)                                 # the grid's own cells, in linear cell order
     for c in range(ncells):
         b, e = int(starts[c]), int(starts[c + 1])
-        entry = int(g[off_cellslot + c])
+        entry = int(inner[c])
         first, cnt = entry >> 6, entry & 63
-        assert first == slot_base + ((b + c + 1) >> 1) and cnt == min((e - b + 1) // 2, 63)
+        n_real = (e - b + 1) // 2
+        assert first == slot_base + ((b + c + 1) >> 1) and cnt == (n_real if n_real < 62 else 63)
         n_sl = (e - b + 1) // 2
         assert not used[first:first + n_sl].any() and first + n_sl <= nslots   # lists never overlap
         used[first:first + n_sl] = True
