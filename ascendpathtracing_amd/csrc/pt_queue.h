@@ -695,24 +695,26 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SC == kScene
                 const uint64_t b01 = __builtin_amdgcn_ballot_w64(tm0 <= tm1), b02 = __builtin_amdgcn_ballot_w64(tm0 <= tm2),
                                b12 = __builtin_amdgcn_ballot_w64(tm1 <= tm2);
                 const uint64_t x0 = b01 & b02, m0 = x0 & need, m1 = ~x0 & b12 & need, m2 = need & ~(x0 | b12);
-                const float a0 = tm0 + td0, a1 = tm1 + td1, a2 = tm2 + td2;
-                asm("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(tm0) : "v"(a0), "s"(m0));
-                asm("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(tm1) : "v"(a1), "s"(m1));
-                asm("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(tm2) : "v"(a2), "s"(m2));
-                // lin += axis 0 ? inc0 : (axis 1 ? inc1 : inc2), in the bordered table: a step out of the grid lands on an "outside" entry (no count
-                // of the steps left: round 3 kept three 10-bit counters in a register, six vector instructions per turn)
-                uint32_t sel;
-                asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(sel) : "v"(inc2), "v"(inc1), "s"(m1));
-                asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(sel) : "v"(sel), "v"(inc0), "s"(m0));
+                // the crossed axis' boundary parameter and the cell index advance under the axis' own mask: three exec-masked groups of two
+                // instructions (selects on the masks took nine: three sums, three selects for the parameters, two selects and a sum for the index)
                 uint64_t saved;
-                asm volatile("s_and_saveexec_b64 %[sv], %[m]\n\t"
-                             "v_add_u32 %[lin], %[lin], %[sel]\n\t"
+                asm volatile("s_mov_b64 %[sv], exec\n\t"
+                             "s_mov_b64 exec, %[m0]\n\t"
+                             "v_add_f32 %[t0], %[t0], %[d0]\n\t"
+                             "v_add_u32 %[lin], %[lin], %[i0]\n\t"
+                             "s_mov_b64 exec, %[m1]\n\t"
+                             "v_add_f32 %[t1], %[t1], %[d1]\n\t"
+                             "v_add_u32 %[lin], %[lin], %[i1]\n\t"
+                             "s_mov_b64 exec, %[m2]\n\t"
+                             "v_add_f32 %[t2], %[t2], %[d2]\n\t"
+                             "v_add_u32 %[lin], %[lin], %[i2]\n\t"
                              "s_mov_b64 exec, %[sv]"
-                             : [sv] "=&s"(saved), [lin] "+v"(lin)
-                             : [m] "s"(need), [sel] "v"(sel)
-                             : "scc");
+                             : [sv] "=&s"(saved), [t0] "+v"(tm0), [t1] "+v"(tm1), [t2] "+v"(tm2), [lin] "+v"(lin)
+                             : [m0] "s"(m0), [m1] "s"(m1), [m2] "s"(m2), [d0] "v"(td0), [d1] "v"(td1), [d2] "v"(td2), [i0] "v"(inc0), [i1] "v"(inc1), [i2] "v"(inc2));
                 // nothing nearer can lie ahead
-                stopm = need & __builtin_amdgcn_ballot_w64(tmin < te - (1e-3f * fabsf(te) + walk_margin));
+                // (te > 0 in a walk: te - (1e-3 * te + margin) as one fused multiply-add -- this is the walk's own conservative criterion, not
+                // reference arithmetic; the margins are orders of magnitude above a rounding)
+                stopm = need & __builtin_amdgcn_ballot_w64(tmin < __builtin_fmaf(te, 0.999f, -walk_margin));
                 const uint64_t go = need & ~stopm;
                 // cellslot[lin] -> the next cell's POSITION range (fetch_range()), for the lanes of `go`; the value is needed at once
                 uint32_t cnt;
