@@ -635,7 +635,7 @@ APT_HD void path_uniforms(uint64_t seed, uint64_t path, double &u1, double &u2) 
 // (lists of ceil(k / 2) slots never overlap under this rule -- no second scan; the few gap slots stay zero and are never read).
 // cellslot is indexed by BORDERED cell coordinates, ((z + 1) * (n1 + 2) + (y + 1)) * (n0 + 2) + (x + 1): one layer of cells around the grid holds
 // kGridCellOutside, so that a walk that leaves the box reads "outside" where it reads the next cell's range and keeps no count of the steps it has
-// left (round 4: six vector instructions per loop turn of the walk).  An inner entry = slot_begin << 6 | slots of the cell, or | 63 for "62 or more:
+// left (round 4: six vector instructions per loop turn of the walk).  An inner entry = slot_begin << 7 | slots of the cell, or | 63 for "62 or more:
 // take the count from cell_start" (62 in the count field is the outside mark).
 // off_cellslot == 0: the tables are absent (they would not fit 26 bits of slot index) and the walk uses item_geom.
 struct GridHeader {
@@ -650,6 +650,7 @@ struct GridHeader {
 };
 constexpr uint32_t kGridSlotCountBits = 6;       // cellslot: low bits = slots of the cell, saturating
 constexpr uint32_t kGridSlotCountMax = (1u << kGridSlotCountBits) - 1u;
+constexpr uint32_t kGridSlotShift = kGridSlotCountBits + 1u;   // cellslot: slot_begin << 7, i.e. (entry >> 6) IS the list's first POSITION (2 per slot): one shift in the walk
 constexpr uint32_t kGridCellOutside = kGridSlotCountMax - 1u;   // cellslot entry of the border layer (count field 62, slot 0)
 APT_HD uint32_t grid_bordered_cells(const uint32_t n[3]) { return (n[0] + 2u) * (n[1] + 2u) * (n[2] + 2u); }
 constexpr uint32_t kGridNoSphere = 0xffffffffu;  // id of a pad
@@ -695,7 +696,7 @@ inline size_t grid_header_offsets(GridHeader &h, uint32_t nitems) { // -> total 
     const uint64_t nslots = (uint64_t)h.slot_base + (((uint64_t)nitems + h.ncells + 1u) >> 1) + 1u;
     const uint64_t off_cellslot = words, off_slots = (off_cellslot + grid_bordered_cells(h.n) + 7u) & ~(uint64_t)7u;   // 32-byte aligned slots
     const uint64_t off_ids = off_slots + nslots * 8u, off_s8 = (off_ids + nslots * 2u + 7u) & ~(uint64_t)7u, end = off_s8 + 8ull * h.num_spheres;
-    if (nslots < (1ull << (32 - kGridSlotCountBits)) && end < (1ull << 32)) {
+    if (nslots < (1ull << (32 - kGridSlotShift)) && end < (1ull << 32)) {
         h.off_cellslot = (uint32_t)off_cellslot; h.off_slots = (uint32_t)off_slots; h.off_slot_ids = (uint32_t)off_ids; h.nslots = (uint32_t)nslots;
         h.off_sphere8 = (uint32_t)off_s8;
         words = (size_t)end;
@@ -707,7 +708,7 @@ inline size_t grid_header_offsets(GridHeader &h, uint32_t nitems) { // -> total 
 APT_HD uint32_t grid_slot_begin(const GridHeader &h, uint32_t cell_start_c, uint32_t c) { return h.slot_base + ((cell_start_c + c + 1u) >> 1); }
 APT_HD uint32_t grid_cellslot_entry(const GridHeader &h, uint32_t b, uint32_t e, uint32_t c) {
     const uint32_t n = (e - b + 1u) >> 1;
-    return grid_slot_begin(h, b, c) << kGridSlotCountBits | (n < kGridCellOutside ? n : kGridSlotCountMax);
+    return grid_slot_begin(h, b, c) << kGridSlotShift | (n < kGridCellOutside ? n : kGridSlotCountMax);
 }
 // The slots of one sorted id list (n ids from `ids`), starting at slot `slot`; geometry from the geom[] table already in the buffer.
 APT_HD void grid_fill_slots(uint32_t *w, const GridHeader &h, uint32_t slot, const uint32_t *ids, uint32_t n) {

@@ -601,7 +601,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SC == kScene
         uint32_t pend = kNoPos;                                 // position of a candidate that tied with the running minimum (see test_pair)
         float tm0 = 0.f, tm1 = 0.f, tm2 = 0.f, td0 = 0.f, td1 = 0.f, td2 = 0.f;
         int inc0 = 0, inc1 = 0, inc2 = 0;                       // linear cell index increment per axis step
-        uint32_t lin = 0, cur = 0, end = 0;                     // cell (index into the BORDERED cellslot table), POSITION cursor / end (2 per slot)
+        uint32_t lin = 0, cur = 0, end = 0;                     // cell (BYTE offset into the BORDERED cellslot table), POSITION cursor / end (2 per slot)
         uint32_t n_cells = 0, n_tests = 0;                      // statistics
         uint64_t walking = 0, has_seg = 0;                      // lanes in a walk / lanes whose registers hold a (finished or running) segment
         auto lane_in = [&](uint64_t m) __attribute__((always_inline)) -> bool { return select_const(m, 1) != 0; };
@@ -651,15 +651,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SC == kScene
         };
         // cellslot[lin] -> the cell's POSITION range [cur, end) in the pair-slot tables
         // a long list's slot count from cell_start (rare: clustered scenes); `lb`: bordered cell index -> the grid's own linear cell index
-        auto long_count = [&](uint32_t lb) __attribute__((always_inline)) -> uint32_t {
+        auto long_count = [&](uint32_t lin4) __attribute__((always_inline)) -> uint32_t {
+            const uint32_t lb = lin4 >> 2;
             const uint32_t n0 = __float_as_uint(hl[1].w), n1 = __float_as_uint(hl[2].w), sx = n0 + 2u, sy = n1 + 2u;
             const uint32_t xb = lb % sx, yb = (lb / sx) % sy, zb = lb / (sx * sy);
             const uint32_t c = ((zb - 1u) * n1 + (yb - 1u)) * n0 + (xb - 1u);
             return (cell_start[c + 1] - cell_start[c] + 1u) >> 1;
         };
         auto fetch_range = [&]() __attribute__((always_inline)) {
-            const uint32_t cs = cellslot[lin];
-            cur = (cs >> kGridSlotCountBits) << 1;
+            const uint32_t cs = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(cellslot) + lin);
+            cur = cs >> kGridSlotCountBits;                    // = 2 * slot_begin (kGridSlotShift)
             uint32_t cnt = cs & kGridSlotCountMax;
             if (cnt == kGridSlotCountMax) cnt = long_count(lin);   // a long list (clustered scenes)
             end = cur + 2u * cnt;
@@ -719,18 +720,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SC == kScene
                 // cellslot[lin] -> the next cell's POSITION range (fetch_range()), for the lanes of `go`; the value is needed at once
                 uint32_t cnt;
                 asm volatile("s_and_saveexec_b64 %[sv], %[m]\n\t"
-                             "v_lshlrev_b32 %[cnt], 2, %[lin]\n\t"
-                             "global_load_dword %[cnt], %[cnt], %[base]\n\t"
+                             "global_load_dword %[cnt], %[lin], %[base]\n\t"
                              "s_waitcnt vmcnt(0)\n\t"
-                             "v_lshrrev_b32 %[cur], 5, %[cnt]\n\t"
-                             "v_and_b32 %[cur], 0x7fffffe, %[cur]\n\t"
+                             "v_lshrrev_b32 %[cur], 6, %[cnt]\n\t"
                              "v_and_b32 %[cnt], 63, %[cnt]\n\t"
                              "v_lshl_add_u32 %[end], %[cnt], 1, %[cur]\n\t"
                              "s_mov_b64 exec, %[sv]"
                              : [sv] "=&s"(saved), [cur] "+v"(cur), [end] "+v"(end), [cnt] "=&v"(cnt)
                              : [m] "s"(go), [lin] "v"(lin), [base] "s"(cellslot)
                              : "scc", "memory");
-                static_assert(kGridSlotCountBits == 6 && kGridSlotCountMax == 63, "the shifts and masks of the block above");
+                static_assert(kGridSlotCountBits == 6 && kGridSlotShift == 7 && kGridSlotCountMax == 63, "the shifts and masks of the block above");
                 // ... or the step has left the grid: the border layer's entry (the count field's two top values: "outside" and "long list")
                 const uint64_t special = go & __builtin_amdgcn_ballot_w64(cnt >= kGridCellOutside);
                 if (special != 0) {
@@ -951,11 +950,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SC == kScene
                             tdel = moves ? cellw * fabsf(inv) : 3.0e38f;
                             inc = fwd ? stride : -stride;
                         };
-                        const int sx = n0 + 2, sy = n1 + 2;         // strides of the bordered table
-                        axis(e0, s.dxy.x, ix, hc.x, c0, 1, inc0, tm0, td0);
-                        axis(e1, s.dxy.y, iy, hc.y, c1, sx, inc1, tm1, td1);
-                        axis(e2, s.dz, iz, hc.z, c2, sx * sy, inc2, tm2, td2);
-                        lin = (uint32_t)(((c2 + 1) * sy + (c1 + 1)) * sx + (c0 + 1));
+                        const int sx = n0 + 2, sy = n1 + 2;         // strides of the bordered table; `lin` and its increments are BYTE offsets
+                        axis(e0, s.dxy.x, ix, hc.x, c0, 4, inc0, tm0, td0);
+                        axis(e1, s.dxy.y, iy, hc.y, c1, 4 * sx, inc1, tm1, td1);
+                        axis(e2, s.dz, iz, hc.z, c2, 4 * sx * sy, inc2, tm2, td2);
+                        lin = (uint32_t)(((c2 + 1) * sy + (c1 + 1)) * sx + (c0 + 1)) << 2;
                         // (Requesting this first range before the axis arithmetic and waiting after it -- inline-asm load -- was measured:
                         // 52.5 against 44.7 ms at 64 spp; the asm's memory clobber doubled the spilled scalar registers.)
                         fetch_range();

@@ -73,7 +73,7 @@ static void check_grid(const char *name, std::vector<float> &scene, uint32_t ns)
             const uint32_t b = cells[c], e = cells[c + 1], n = (e - b + 1) >> 1;
             const uint32_t x = c % h.n[0], y = (c / h.n[0]) % h.n[1], z = c / (h.n[0] * h.n[1]);
             const uint32_t entry = cellslot[((z + 1) * sy + (y + 1)) * sx + (x + 1)];
-            const uint32_t slot0 = entry >> apt::kGridSlotCountBits, cnt = entry & apt::kGridSlotCountMax;
+            const uint32_t slot0 = entry >> apt::kGridSlotShift, cnt = entry & apt::kGridSlotCountMax;
             CHECK(slot0 == apt::grid_slot_begin(h, b, c) && cnt == (n < apt::kGridCellOutside ? n : apt::kGridSlotCountMax), "%s: cellslot of cell %u", name, c);
             CHECK((uint64_t)slot0 + n <= h.nslots, "%s: slots of cell %u beyond the table", name, c);
             for (uint32_t i = b; i < e; ++i) {                 // candidate i - b sits in slot slot0 + (i-b)/2, half (i-b)&1

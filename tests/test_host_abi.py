@@ -208,7 +208,7 @@ def test_grid_builder_layout(apt):
     for c in range(ncells):
         b, e = int(starts[c]), int(starts[c + 1])
         entry = int(inner[c])
-        first, cnt = entry >> 6, entry & 63
+        first, cnt = entry >> 7, entry & 63
         n_real = (e - b + 1) // 2
         assert first == slot_base + ((b + c + 1) >> 1) and cnt == (n_real if n_real < 62 else 63)
         n_sl = (e - b + 1) // 2
