@@ -604,7 +604,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SC == kScene
         uint32_t lin = 0, cur = 0, end = 0;                     // cell (BYTE offset into the BORDERED cellslot table), POSITION cursor / end (2 per slot)
         uint32_t n_cells = 0, n_tests = 0;                      // statistics
         uint64_t walking = 0, has_seg = 0;                      // lanes in a walk / lanes whose registers hold a (finished or running) segment
-        auto lane_in = [&](uint64_t m) __attribute__((always_inline)) -> bool { return select_const(m, 1) != 0; };
+        // a wave mask (scalar) as the per-lane condition of a divergent region: the mask itself becomes the execution mask
+        // (llvm.amdgcn.inverse.ballot; the v_cndmask + v_cmp pair of `select_const(m, 1) != 0` cost two vector instructions per use)
+        auto lane_in = [&](uint64_t m) __attribute__((always_inline)) -> bool { return __builtin_amdgcn_inverse_ballot_w64(m); };
         // Two candidates (a pair slot) against the lane's ray; `pos` = position of the first.  Equal keys mean equal t: the lower SPHERE
         // index must win (the reference's strict '<' over ascending indices).  Inside a slot and inside a list the ids ascend, so an
         // earlier candidate beats a later one on a tie by order.  A tie with the running minimum from an EARLIER list -- nearly always
