@@ -509,11 +509,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SC == kScene
     // the cost only grows beyond ~8 lanes, by ~2.2 cycles per L1-missing lane).  The nested form issues ~320 such loads per wave
     // and segment, its float4 candidate loads serving 3.5 lanes on average: the inner loop runs to the longest list of the wave in
     // every cell of the longest walk, and the lanes of finished walks idle until the slowest of 64 is through.
-    // Here a lane is WALKING or WAITING.  A walking lane does one of two things per loop turn: it tests ONE pair slot of its cell
-    // -- two candidates in the packed form of the 8-sphere kernel (intersect_pre2, exact single-rsq square root, integer root
-    // keys) -- or, its list exhausted, leaves the cell (exit test, one DDA step, ONE dword with the next cell's slot range).  A lane
-    // whose walk has ended waits; as soon as `refill_lanes` lanes wait (or nobody walks) the per-segment block runs for all of them
-    // together: shading step, roulette, park / refill from the ray pool, always-tested spheres, slab test, DDA set-up.
+    // Here a lane is WALKING or WAITING.  Per loop turn a walking lane tests ONE pair slot of its cell, if it has one left -- two candidates
+    // in the packed form of the 8-sphere kernel (intersect_pre2, exact single-rsq square root, integer root keys) -- and then, its list
+    // exhausted, leaves the cell (exit test, one DDA step, ONE dword with the next cell's slot range; a step out of the grid reads the
+    // border layer's "outside" entry).  A lane whose walk has ended waits; as soon as `refill_lanes` lanes wait (or nobody walks) the
+    // per-segment block runs for all of them together: shading step, roulette, park / refill from the ray pool, always-tested spheres
+    // (through shared planes when they are the reference room), DDA set-up.
     // The arg-min carries (root key, position of the candidate): equal keys inside a list resolve by order (ids ascend there); a tie
     // with the minimum of an earlier list is recorded and settled by the two sphere ids when the segment is shaded (test_pair below).
     // Exactness: operation for operation intersect_pre / correctly rounded square root / select_root; a discriminant outside the
