@@ -104,7 +104,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SC == kScene
                                                                  LeafProg lp, QueueArgs qa) {
     extern __shared__ __align__(16) unsigned char qlds[];
     constexpr uint32_t kPool = queue_pool_entries(SC == kSceneGrid), kPoolBatch = kPool;
-    float4 *tab = reinterpret_cast<float4 *>(qlds + queue_lds_off_tab(kPool));
+    // (an LDS pointer made from the integer offset: the dynamic region starts at LDS address 0 -- checked below --, and through `qlds` every table
+    // address carried an add of the symbol's link-time value, a v_add_u32 with 0 per bounce)
+    typedef __attribute__((address_space(3))) float4 lds_float4;
+    float4 *tab = (float4 *)(lds_float4 *)(uintptr_t)queue_lds_off_tab(kPool);
     CameraLite &cam = *reinterpret_cast<CameraLite *>(qlds + queue_lds_off_cam(kPool));
     const uint32_t lane = threadIdx.x;
     // No static LDS in this kernel, so the dynamic region starts at LDS address 0 (tests/test_isa_hazards.py checks the kernel
@@ -176,7 +179,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SC == kScene
         path_uniforms_at(splitmix64(fa.seed) + base * kPathStride + (uint64_t)off * kPathStride, u1, u2);
         float rox, roy, roz, rdx, rdy, rdz;
         camera_ray(cam, fa.width, fa.height, g_pi, g_pj, sub >> 1, sub & 1u, u1, u2, rox, roy, roz, rdx, rdy, rdz);
-        const uint32_t e = (pool_head + pool_level + lane) & (kPool - 1u);
+        // (a batch is generated only into an EMPTY pool -- kPoolBatch == kPool --, so it always starts at entry 0 and the FIFO never wraps)
+        static_assert(kPoolBatch == kPool, "gen_batch restarts the pool at entry 0");
+        pool_head = 0;
+        const uint32_t e = pool_level + lane;
         if (on) {
             pool_a[e] = make_float4(rox, roy, rdx, rdy);
             const uint32_t ca = qlds_base + colq_off + g_buf * qa.buf_bytes + i * 12u + sub * 4u;
@@ -317,7 +323,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SC == kScene
             const uint64_t take = want & __builtin_amdgcn_ballot_w64(rank < pool_level);
             uint32_t ea;   // ((head + rank) * 16) mod 2048: one v_lshl_add_u32 with the scalar head * 16, one v_and
             asm("v_lshl_add_u32 %0, %1, 4, %2" : "=v"(ea) : "v"(rank), "s"(pool_head << 4));
-            ea &= (kPool - 1u) << 4;
             uint64_t saved;
             if (!rr) {
                 asm volatile("s_and_saveexec_b64 %[sv], %[m]\n\t"
@@ -361,7 +366,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SC == kScene
                 key = ((uint64_t)khi << 32) | klo;
             }
             const uint32_t nt = min((uint32_t)__popcll(want), pool_level);
-            pool_head = (pool_head + nt) & (kPool - 1u);
+            pool_head += nt;
             pool_level -= nt;
             issued += nt;
             active |= take;
