@@ -26,7 +26,7 @@ ABI_SYMBOLS = ["apt_default_params", "render_do", "apt_set_default_params", "ren
                "apt_context_render_do", "apt_context_render_do_ex", "apt_context_render_frame",
                "apt_multi_create", "apt_multi_render", "apt_multi_destroy",
                "apt_decode_color_band", "apt_mt19937_checkpoints_window", "apt_gen_rays_mt_device_ex", "apt_build_grid_device", "apt_render_frame_mt",
-               "apt_context_check", "apt_check", "apt_context_set_debug", "apt_set_debug"]
+               "apt_context_check", "apt_check", "apt_context_set_debug", "apt_set_debug", "apt_context_get_debug", "apt_get_debug"]
 # the reference declares render_do with C++ linkage (src/main.cpp:9-10): the mangled symbol is exported too
 CXX_RENDER_DO = "_Z9render_dojPvS_PhS0_S0_"
 ABI_VERSION = 3

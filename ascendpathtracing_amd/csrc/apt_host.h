@@ -58,6 +58,7 @@ struct apt_context {
     void set_trace_counter(unsigned long long *c);
     void set_refill_lanes(uint32_t lanes);
     int set_debug(const char *key, double value); // APT_OK / APT_ERR_ARG (error record set)
+    int get_debug(const char *key, double *value); // the knob's current value (what set_debug last stored, or the environment's initial value)
 
     // The device status word of this context on device `dev` (render_kernels.hip: kernels OR failure bits into it, apt_context_check()
     // reads and clears it).  Device memory the context owns; `lookup` only returns what exists, `adopt` stores a freshly made word and

@@ -82,6 +82,19 @@ int apt_context::set_debug(const char *key, double value) {
 range:
     return apt::set_error(APT_ERR_ARG, "apt_context_set_debug: value out of range for '%s'", key);
 }
+int apt_context::get_debug(const char *key, double *value) {
+    if (!key) return apt::set_error(APT_ERR_ARG, "apt_context_get_debug: key is null%s");
+    const std::string k(key);
+    std::lock_guard<std::mutex> g(m_);
+    const apt::Debug &d = v_.debug;
+    if (k == "queue_ppw") *value = d.queue_ppw;
+    else if (k == "queue_nbuf") *value = d.queue_nbuf;
+    else if (k == "queue_lds_pad") *value = d.queue_lds_pad;
+    else if (k == "grid_walk") *value = d.grid_walk;
+    else if (k == "grid_spheres_per_cell") *value = d.grid_spheres_per_cell;
+    else return apt::set_error(APT_ERR_ARG, "apt_context_get_debug: unknown key '%s'", key);
+    return APT_OK;
+}
 uint32_t *apt_context::status_lookup(int dev) {
     if (dev < 0 || dev >= apt::kMaxStatusDevices) return nullptr;
     std::lock_guard<std::mutex> g(m_);

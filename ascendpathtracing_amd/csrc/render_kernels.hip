@@ -52,6 +52,7 @@ int check_params(const apt_render_params *p) {
 uint32_t *status_word(apt_context &ctx, hipStream_t st) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    if (dev < 0 || dev >= apt::kMaxStatusDevices) return nullptr;   // beyond the table: no word (and no allocation per launch)
     if (uint32_t *w = ctx.status_lookup(dev)) return w;
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(st, &cs) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
@@ -325,6 +326,12 @@ int apt_context_set_debug(apt_context *ctx, const char *key, double value) {
     return ctx->set_debug(key, value);
 }
 
+int apt_context_get_debug(apt_context *ctx, const char *key, double *value) {
+    clear_error();
+    if (!ctx || !value) return fail(APT_ERR_ARG, "context/value is null%s");
+    return ctx->get_debug(key, value);
+}
+
 // Reads and clears the status word of the current device (see the header).  Synchronises `stream` first.
 int apt_context_check(apt_context *ctx, void *stream) {
     clear_error();
@@ -400,6 +407,7 @@ int apt_set_default_params(const apt_render_params *p) { return apt_context_set_
 int apt_set_refill_lanes(uint32_t lanes) { return apt_context_set_refill_lanes(&apt::default_context(), lanes); }
 int apt_set_trace_counter(uint64_t *device_counter) { return apt_context_set_trace_counter(&apt::default_context(), device_counter); }
 int apt_set_debug(const char *key, double value) { return apt_context_set_debug(&apt::default_context(), key, value); }
+int apt_get_debug(const char *key, double *value) { return apt_context_get_debug(&apt::default_context(), key, value); }
 int apt_check(void *stream) { return apt_context_check(&apt::default_context(), stream); }
 
 int render_do_ex(const apt_render_params *p, void *stream, const float *rays, const float *spheres, float *colors) {

@@ -65,6 +65,7 @@ class FrameShard:
         self._on_gpu = str(self.device).startswith("cuda")
         self._side = torch.cuda.Stream(device=self.device) if (self._on_gpu and rank == 0) else None   # the unpack runs beside the next render
         self._unpacked = {}            # slot -> event: its receive buffer has been read by the unpack
+        self._sent = {}                # slot -> event: the collective that reads this slot's packed buffer (the root's own send buffer) is done
         self._marks = []               # (wait begin, wait end = unpack begin, unpack end)
 
     # ---- layout ------------------------------------------------------------------------------------
@@ -104,8 +105,20 @@ class FrameShard:
         return fb, u8
 
     # ---- render + gather -----------------------------------------------------------------------------
-    def render(self, slot_views, spheres, render_fn, params=None):
-        """One launch per stripe of this rank, straight into the packed buffer's views."""
+    def begin(self, slot=None):
+        """Before anything writes into packed buffer `slot` again (None: any slot): the current stream waits until the last gather
+        that read it has completed.  Other ranks wait for their collective on the current stream in finish(); the root waits for it
+        on its side stream only, so without this the render of frame k could overwrite the buffer the gather of frame k - slots is
+        still sending from."""
+        for k in ([slot] if slot is not None else list(self._sent)):
+            ev = self._sent.pop(k, None)
+            if ev is not None:
+                torch.cuda.current_stream().wait_event(ev)
+
+    def render(self, slot_views, spheres, render_fn, params=None, slot=None):
+        """One launch per stripe of this rank, straight into the packed buffer's views (`slot`: which packed buffer they belong
+        to; unknown = wait for every outstanding gather of this rank's buffers first)."""
+        self.begin(slot)
         p = self.params if params is None else params
         for (b, c), (fb, u8) in zip(self.ranges, slot_views):
             render_fn(p, spheres, b, c, fb=fb, fb_u8=u8)
@@ -156,7 +169,7 @@ class FrameShard:
         unequal: every rank's buffer has the same padded size."""
         self.finish()
         if self.world == 1 and not dist.is_initialized():
-            self._pending = ("local", slot, full_fb, full_u8)
+            self._pending = ("local", slot, full_fb, full_u8, None)
             return
         if self.rank == 0:
             if slot in self._unpacked:       # the slot's receive buffer may still be read by the unpack of two frames ago (side stream)
@@ -164,7 +177,11 @@ class FrameShard:
             work = dist.gather(self._bufs[slot], self._lists[slot], dst=0, async_op=True)
         else:
             work = dist.gather(self._bufs[slot], None, dst=0, async_op=True)
-        self._pending = (work, slot, full_fb, full_u8)
+        ready = None
+        if self._side is not None:     # what the side stream must see before it unpacks: the frame tensors, made on the current stream
+            ready = torch.cuda.Event()                            # BEFORE the next render is queued behind this call
+            ready.record()
+        self._pending = (work, slot, full_fb, full_u8, ready)
 
     def finish(self):
         """Wait for the pending gather (if any) and, on the root, scatter the stripes into the frame.  On a GPU the wait and the
@@ -172,7 +189,7 @@ class FrameShard:
         current stream joins the side stream in drain()."""
         if self._pending is None:
             return
-        work, slot, full_fb, full_u8 = self._pending
+        work, slot, full_fb, full_u8, ready = self._pending
         self._pending = None
         if work == "local":
             if full_fb is not None:
@@ -190,11 +207,15 @@ class FrameShard:
             self._marks.append((t0, t1, time.perf_counter()))
             return
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
-        self._side.wait_stream(torch.cuda.current_stream())       # (the frame tensors were made on the current stream)
+        # The side stream waits for the current stream as it stood when the gather was ISSUED (the frame tensors exist), not as it
+        # stands now: the next frame's render is usually queued already, and waiting for it would serialise the unpack behind it
+        # and make gather_wait_ms read 0.
+        self._side.wait_event(ready)
         with torch.cuda.stream(self._side):
             ev[0].record()
             work.wait()                                           # the side stream waits for the collective
             ev[1].record()
+            self._sent[slot] = ev[1]                              # begin(slot): the current stream waits for it before the slot is rendered again
             if full_fb is not None:
                 self._unpack(self._recv[slot], full_fb, full_u8)
             ev[2].record()
@@ -207,8 +228,8 @@ class FrameShard:
             torch.cuda.current_stream().wait_stream(self._side)
 
     def timings(self):
-        """Root: mean milliseconds per finished gather spent (a) waiting for the collective after the next render had been queued and
-        (b) scattering the stripes into the frame -> {"gather_wait_ms", "unpack_ms", "gathers"}; call after a device synchronise."""
+        """Root: mean milliseconds per finished gather between (a) the side stream being free to look at it (the frame's own render
+        done) and the collective's completion, and (b) scattering the stripes into the frame -> {"gather_wait_ms", "unpack_ms", "gathers"}; call after a device synchronise."""
         if not self._marks:
             return {"gather_wait_ms": None, "unpack_ms": None, "gathers": 0}
         if self._side is None:

@@ -70,6 +70,11 @@ class Context:
     def set_debug(self, key, value):
         check(lib().apt_context_set_debug(self._h, key.encode(), ctypes.c_double(value)), "apt_context_set_debug")
 
+    def get_debug(self, key):
+        v = ctypes.c_double(0)
+        check(lib().apt_context_get_debug(self._h, key.encode(), ctypes.byref(v)), "apt_context_get_debug")
+        return v.value
+
     def check(self, stream=None):
         """apt_context_check: waits for `stream`, raises AptError when a kernel of this context reported a failure through the
         device status word (the reference asserts inside its kernel, src/render.cpp:68-73)."""
@@ -166,19 +171,28 @@ def set_debug(key, value):
     check(lib().apt_set_debug(key.encode(), ctypes.c_double(value)), "apt_set_debug")
 
 
+def get_debug(key):
+    """The knob's current value in the default context (apt_get_debug)."""
+    v = ctypes.c_double(0)
+    check(lib().apt_get_debug(key.encode(), ctypes.byref(v)), "apt_get_debug")
+    return v.value
+
+
 class debug_knob:
-    """with debug_knob("grid_walk", 1): ...  -- sets a knob of the default context and resets it to 0 on the way out, also after an
-    exception (tests select kernels this way, never through the process environment)."""
+    """with debug_knob("grid_walk", 1): ...  -- sets a knob of the default context and puts back the value it FOUND on the way out
+    (an initial value from the environment, or an enclosing debug_knob's), also after an exception (tests select kernels this way,
+    never through the process environment)."""
 
     def __init__(self, key, value):
-        self.key, self.value = key, value
+        self.key, self.value, self.before = key, value, 0
 
     def __enter__(self):
+        self.before = get_debug(self.key)
         set_debug(self.key, self.value)
         return self
 
     def __exit__(self, *exc):
-        set_debug(self.key, 0)
+        set_debug(self.key, self.before)
 
 
 def check_device_status(stream=None):

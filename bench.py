@@ -274,7 +274,7 @@ def dry_run(args):
 
     t0 = time.perf_counter()
     for k in range(args.warmup + args.steps):
-        shard.render(slots[k % 2], None, fake_render)
+        shard.render(slots[k % 2], None, fake_render, slot=k % 2)
         if world > 1:
             shard.gather_async(k % 2, *full)
     shard.finish()
@@ -384,7 +384,7 @@ def main():
     def step(k, events=None):
         if events:
             events[0].record()                # torch's current stream == the stream the kernels are launched on
-        shard.render(slots[k % 2], sph, render.render_frame)
+        shard.render(slots[k % 2], sph, render.render_frame, slot=k % 2)
         if events:
             events[1].record()
         if world > 1:

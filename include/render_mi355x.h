@@ -168,7 +168,9 @@ int  apt_context_set_refill_lanes(apt_context *ctx, uint32_t lanes);
  *   apt_context_check(ctx, stream)  waits for `stream` (synchronising; not capture-safe), reads the word of the current device and
  *       clears it: APT_OK, or APT_ERR_DEVICE with the bits named in apt_last_error().  apt_check(stream) = the default context.
  *   apt_render_host and apt_multi_render check it themselves before they return.
- * The word is allocated on a context's first launch on a device (one hipMalloc of 4 bytes, once; skipped while `stream` is being
+ * The word is allocated on a context's first launch on a device -- through ANY launching entry point, render_do / render_do_ex /
+ * render_frame / apt_render_frame_mt included: the one allocation those otherwise allocation-free calls ever make -- (one hipMalloc of
+ * 4 bytes, once per context and device, device indices 0..15; a device beyond that runs without a word; skipped while `stream` is being
  * captured -- a context whose FIRST launch on a device happens inside a graph capture runs without the word until a launch or an
  * apt_context_check outside a capture has made it). */
 enum {
@@ -184,9 +186,12 @@ int  apt_check(void *stream);
  *   "queue_ppw" 1..4096 pixels per wave of the sample-queue kernels    "queue_nbuf" 2..16 colour buffers    "queue_lds_pad" bytes
  *   "grid_walk" 1 = frames of a scene behind a grid use render_frame_kernel's nested item walk only (bit-identical, slower)
  *   "grid_spheres_per_cell" cell size of apt_build_grid_host / apt_build_grid_device (default context's value)
- * APT_ERR_ARG for an unknown key or a value out of range.  apt_set_debug = the default context. */
+ * APT_ERR_ARG for an unknown key or a value out of range.  apt_set_debug = the default context.
+ * apt_context_get_debug / apt_get_debug read a knob's current value (so that a caller can restore what it found). */
 int  apt_context_set_debug(apt_context *ctx, const char *key, double value);
 int  apt_set_debug(const char *key, double value);
+int  apt_context_get_debug(apt_context *ctx, const char *key, double *value);
+int  apt_get_debug(const char *key, double *value);
 void apt_context_render_do(apt_context *ctx, uint32_t blockDim, void *l2ctrl, void *stream,
                            uint8_t *rays, uint8_t *spheres, uint8_t *colors);
 int  apt_context_render_do_ex(apt_context *ctx, const apt_render_params *p, void *stream,

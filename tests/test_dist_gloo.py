@@ -61,7 +61,7 @@ def _worker_pipelined(rank, world, port, out_path, w=8, h=6, stripes=1):
     full = None
     for k in range(3):
         p = apt.make_params(w, h, 1, depth=3, seed=k)
-        shard.render(slots[k % 2], sph, _oracle_render_fn, params=p)
+        shard.render(slots[k % 2], sph, _oracle_render_fn, params=p, slot=k % 2)
         full = shard.alloc_full() if rank == 0 else (None, None)
         shard.gather_async(k % 2, *full)      # also completes frame k-1
         frames.append(full)

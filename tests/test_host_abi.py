@@ -72,6 +72,32 @@ def test_debug_knobs_argument_checks_without_a_gpu(apt):
     lib.apt_context_destroy(ctx)
 
 
+def test_debug_knob_reads_back_and_restores_what_it_found(apt):
+    """debug_knob reset a knob to 0 on exit, losing an initial value from the environment or an enclosing block."""
+    from ascendpathtracing_amd import render
+    lib = apt._lib.lib()
+    ctx = render.Context()
+    ctx.set_debug("queue_ppw", 24)
+    ctx.set_debug("grid_spheres_per_cell", 0.7)
+    assert ctx.get_debug("queue_ppw") == 24 and ctx.get_debug("grid_spheres_per_cell") == 0.7 and ctx.get_debug("grid_walk") == 0
+    with pytest.raises(apt.AptError):
+        ctx.get_debug("nope")
+    v = ctypes.c_double(-1)
+    assert lib.apt_context_get_debug(None, b"queue_ppw", ctypes.byref(v)) == 1 and lib.apt_get_debug(b"queue_ppw", None) == 1
+    ctx.close()
+    before = render.get_debug("queue_ppw")
+    try:
+        render.set_debug("queue_ppw", 8)
+        with render.debug_knob("queue_ppw", 32):
+            assert render.get_debug("queue_ppw") == 32
+            with render.debug_knob("queue_ppw", 4):
+                assert render.get_debug("queue_ppw") == 4
+            assert render.get_debug("queue_ppw") == 32
+        assert render.get_debug("queue_ppw") == 8
+    finally:
+        render.set_debug("queue_ppw", before)
+
+
 def test_params_struct_layout_matches_header(apt):
     p = apt.default_params()
     assert ctypes.sizeof(apt.RenderParams) == 80 == p.struct_size
