@@ -14,8 +14,8 @@ reference's own interfaces for that path:
 There is no CPU fallback: every compute entry raises if the HIP library or a GPU is missing.
 """
 from . import _lib  # noqa: F401
-from ._lib import (APT_FLAG_RETIRE, APT_FLAG_RR, APT_FLAG_EMISSION, APT_FLAG_BAND_BUFFERS, APT_MODE_KERNEL, APT_MODE_ORACLE, RenderParams, AptError, default_params,
+from ._lib import (APT_FLAG_RETIRE, APT_FLAG_RR, APT_FLAG_EMISSION, APT_FLAG_BAND_BUFFERS, APT_FLAG_GRID_SLOTS, APT_MODE_KERNEL, APT_MODE_ORACLE, RenderParams, AptError, default_params,
                    make_params)
 
-__all__ = ["APT_FLAG_RETIRE", "APT_FLAG_RR", "APT_FLAG_EMISSION", "APT_FLAG_BAND_BUFFERS", "APT_MODE_KERNEL", "APT_MODE_ORACLE", "RenderParams", "AptError", "default_params",
+__all__ = ["APT_FLAG_RETIRE", "APT_FLAG_RR", "APT_FLAG_EMISSION", "APT_FLAG_BAND_BUFFERS", "APT_FLAG_GRID_SLOTS", "APT_MODE_KERNEL", "APT_MODE_ORACLE", "RenderParams", "AptError", "default_params",
            "make_params"]

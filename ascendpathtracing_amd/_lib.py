@@ -13,8 +13,9 @@ APT_FLAG_RETIRE = 1
 APT_FLAG_RR = 2
 APT_FLAG_EMISSION = 4
 APT_FLAG_BAND_BUFFERS = 8
+APT_FLAG_GRID_SLOTS = 16
 APT_ERR_DEVICE = 4
-APT_DEV_QUEUE_GUARD, APT_DEV_GRID_TURNS, APT_DEV_LDS_BASE = 1, 2, 4      # bits of the device status word (apt_context_check)
+APT_DEV_QUEUE_GUARD, APT_DEV_GRID_TURNS, APT_DEV_LDS_BASE, APT_DEV_GRID_MISMATCH = 1, 2, 4, 8      # bits of the device status word (apt_context_check)
 
 # every symbol include/render_mi355x.h declares
 ABI_SYMBOLS = ["apt_default_params", "render_do", "apt_set_default_params", "render_do_ex", "render_frame",
@@ -26,7 +27,7 @@ ABI_SYMBOLS = ["apt_default_params", "render_do", "apt_set_default_params", "ren
                "apt_context_render_do", "apt_context_render_do_ex", "apt_context_render_frame",
                "apt_multi_create", "apt_multi_render", "apt_multi_destroy",
                "apt_decode_color_band", "apt_mt19937_checkpoints_window", "apt_gen_rays_mt_device_ex", "apt_build_grid_device", "apt_render_frame_mt",
-               "apt_context_check", "apt_check", "apt_context_set_debug", "apt_set_debug", "apt_context_get_debug", "apt_get_debug"]
+               "apt_context_check", "apt_check", "apt_context_set_debug", "apt_set_debug", "apt_context_get_debug", "apt_get_debug", "apt_grid_flags"]
 # the reference declares render_do with C++ linkage (src/main.cpp:9-10): the mangled symbol is exported too
 CXX_RENDER_DO = "_Z9render_dojPvS_PhS0_S0_"
 ABI_VERSION = 3

@@ -295,6 +295,14 @@ int apt_gen_scene_host(uint32_t num_spheres, uint64_t seed, float *spheres, size
 // so that any ray the fp32 intersection formula can possibly accept passes through the interior of a
 // cell that lists the sphere (the formula's absolute error on disc is ~1e-3 at these coordinates; the
 // margin is 0.05 + 1e-4 * coordinate scale).  Cells are sized for kGridSpheresPerCell = 0.5 sphere centres each (apt_set_debug("grid_spheres_per_cell", v) overrides: tuning knob).
+uint32_t apt_grid_flags(const void *grid_head_host, uint32_t num_spheres) {
+    apt::clear_error();
+    if (!grid_head_host) return 0u;
+    apt::GridHeader h;
+    memcpy(&h, grid_head_host, sizeof h);
+    return (h.magic == apt::kGridMagic && h.num_spheres == num_spheres && h.off_cellslot != 0u) ? (uint32_t)APT_FLAG_GRID_SLOTS : 0u;
+}
+
 int apt_build_grid_host(const float *sph, uint32_t ns, void *grid, size_t *out_bytes) {
     apt::clear_error();
     if (!sph || ns == 0 || !out_bytes) return set_error(APT_ERR_ARG, "apt_build_grid_host: spheres/out_bytes must be non-null, num_spheres non-zero%s");

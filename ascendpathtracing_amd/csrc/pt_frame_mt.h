@@ -61,12 +61,13 @@ __global__ __launch_bounds__(kBlock, APT_TWO_WAVES) void render_frame_mt_kernel(
     const bool planes = sc.planes;
     const Gain3 gain = load_gain(sph, ta);
     const uint32_t S = 1u << ma.log2_s, H = fa.height;
-    const uint64_t group = ma.first_group + blockIdx.x;
+    const uint32_t blk = xcd_contiguous_block(blockIdx.x, gridDim.x);   // (XCD-aware: neighbouring pixel groups through one L2)
+    const uint64_t group = ma.first_group + blk;
     const uint32_t npaths = 312u * S;                           // of this group
     const uint64_t q0 = group * kMtGroupPixels;                 // first pixel
     const uint32_t i0 = (uint32_t)(q0 / H), j0 = (uint32_t)(q0 % H);
     const uint64_t pix_end = fa.pixel_begin + fa.pixel_count;
-    for (uint32_t i = t; i < 624; i += kBlock) ring[i] = ma.checkpoints[(uint64_t)blockIdx.x * 624 + i];   // y[0 .. 623] = the state of the group's first block
+    for (uint32_t i = t; i < 624; i += kBlock) ring[i] = ma.checkpoints[(uint64_t)blk * 624 + i];   // y[0 .. 623] = the state of the group's first block
     __syncthreads();
 
     uint32_t have = 624;                                        // words y[0 .. have) exist
@@ -194,12 +195,13 @@ __global__ __launch_bounds__(kBlock, APT_TWO_WAVES) void render_frame_mt_any_ker
     const bool planes = sc.planes;
     const Gain3 gain = load_gain(sph, ta);
     const uint32_t S = fa.samples, H = fa.height, nleaves = lp.nleaves;
-    const uint64_t group = ma.first_group + blockIdx.x;
+    const uint32_t blk = xcd_contiguous_block(blockIdx.x, gridDim.x);   // (XCD-aware: neighbouring pixel groups through one L2)
+    const uint64_t group = ma.first_group + blk;
     const uint32_t npaths = 312u * S;                           // of this group
     const uint64_t q0 = group * kMtGroupPixels;                 // first pixel
     const uint32_t i0 = (uint32_t)(q0 / H), j0 = (uint32_t)(q0 % H);
     const uint64_t pix_end = fa.pixel_begin + fa.pixel_count;
-    for (uint32_t i = t; i < 624; i += kBlock) ring[i] = ma.checkpoints[(uint64_t)blockIdx.x * 624 + i];   // y[0 .. 623] = the state of the group's first block
+    for (uint32_t i = t; i < 624; i += kBlock) ring[i] = ma.checkpoints[(uint64_t)blk * 624 + i];   // y[0 .. 623] = the state of the group's first block
     __syncthreads();
 
     uint32_t have = 624;                                        // words y[0 .. have) exist

@@ -113,7 +113,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SC == kScene
     // No static LDS in this kernel, so the dynamic region starts at LDS address 0 (tests/test_isa_hazards.py checks the kernel
     // descriptor's group_segment_fixed_size); a build that breaks this renders nothing rather than reading the wrong pool entries.
     if ((uint32_t)(uintptr_t)qlds != 0u) { report_status(ta, APT_DEV_LDS_BASE); return; }
-    if (SC == kSceneGrid && !grid_queue_usable(ta)) return;            // wave-uniform: render_frame_kernel renders this frame (grid_walk == 2)
+    if (SC == kSceneGrid && !grid_queue_usable(ta)) {                  // wave-uniform: render_frame_kernel renders this frame (its grid_walk == 2) --
+        if (ta.grid_walk == 3u) report_status(ta, APT_DEV_GRID_MISMATCH);   // or, under APT_FLAG_GRID_SLOTS, nobody does: the caller's promise did not hold
+        return;
+    }
     if (lane == 0) cam = camera_lite(fa.cam);
     Scene8 sc;
     Tab8 tab8{tab, tab + 8};
@@ -135,7 +138,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SC == kScene
     __syncthreads();
 
     // this wave's pixels
-    const uint64_t wb = (uint64_t)blockIdx.x * qa.ppw;
+    const uint64_t wb = (uint64_t)xcd_contiguous_block(blockIdx.x, gridDim.x) * qa.ppw;   // (XCD-aware: neighbouring pixels through one L2)
     const uint32_t npx = (uint32_t)min((uint64_t)qa.ppw, fa.pixel_count - wb);
     const uint32_t U = npx * nleaves;                                   // units of this wave
     const uint64_t q0 = fa.pixel_begin + wb;

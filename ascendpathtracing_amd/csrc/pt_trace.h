@@ -70,10 +70,23 @@ struct TraceArgs {
     uint64_t seed;              // keys the roulette draws
     const uint32_t *grid;       // apt_render_params.accel (device) or null
     uint32_t grid_walk;         // frame kernels: 0 = render_frame_kernel walks the grid (nested item walk); 2 = it returns at once when
-                                // the sample-queue kernel's grid form renders this frame (grid_queue_usable)
+                                // the sample-queue kernel's grid form renders this frame (grid_queue_usable); sample-queue kernel:
+                                // 3 = APT_FLAG_GRID_SLOTS, it is the frame's only launch and reports a grid it cannot use
     unsigned long long *traced; // optional device counter of traced segments
     uint32_t *status;           // the context's device status word (include/render_mi355x.h APT_DEV_*), or null
 };
+// Workgroup id -> the block of work it takes, XCD-aware.  The dispatcher hands consecutive workgroup ids to the 8 XCDs of an MI355X in turn,
+// and each XCD has its own L2: with the identity mapping the workgroups that write one 128-byte line of the frame (32 float pixels of a plane,
+// 42 u8 pixels) sit on different XCDs, every L2 holds -- and writes back -- a PART of the line, and HBM saw 1.32x the frame's bytes (round 4:
+// 40.9 MB written for 31.1).  Here XCD x takes the x-th CONTIGUOUS eighth of the blocks, in order, so neighbouring pixels are written
+// through one L2 at about the same time and leave it as whole lines.  Pure relabelling of independent blocks: no effect on any result.
+__device__ __forceinline__ uint32_t xcd_contiguous_block(uint32_t wg, uint32_t nwg) {
+    constexpr uint32_t kXcds = 8;
+    const uint32_t xcd = wg % kXcds, idx = wg / kXcds;
+    const uint32_t q = nwg / kXcds, r = nwg % kXcds;
+    return xcd * q + (xcd < r ? xcd : r) + idx;        // (idx < q + (xcd < r) for every wg < nwg)
+}
+
 // A kernel that has to give up says so (the reference asserts inside its kernel: src/render.cpp:68-73): one lane ORs the bit into the
 // context's status word; apt_context_check() reports it as APT_ERR_DEVICE.
 __device__ __forceinline__ void report_status(const TraceArgs &ta, uint32_t bit) {
@@ -85,6 +98,13 @@ __device__ __forceinline__ void report_status(const TraceArgs &ta, uint32_t bit)
 // so every operation of intersect_pre becomes one v_pk_{add,mul}_f32 over a register pair, the
 // ray component being broadcast to both halves by op_sel (no register shuffles).  Packed fp32
 // ops round exactly like the scalar ones, element by element; contraction is off.
+
+// The "0 +" in front of the shading step's dot product (rt_helper.h:690 Duplicate(0); sdot's `dot = 0.0` in O-mode) only matters when
+// all three products are -0: the sum is then +0 with it and -0 without.  The one consumer is k2 = dot * 2 (:697), and fma(dot, 2, +0)
+// is that product exactly (a doubling never rounds; overflow and NaN go the same way) with -0 turned into +0 by the addend: the start
+// value's whole effect for the price of the multiply itself.  (The norm's products are squares, never -0: nothing to preserve there.)
+__device__ __forceinline__ float twice_canonical(float dot) { return __builtin_fmaf(dot, 2.0f, 0.0f); }
+__device__ __forceinline__ f2 twice_canonical(f2 dot) { return __builtin_elementwise_fma(dot, f2{2.0f, 2.0f}, f2{0.0f, 0.0f}); }
 
 struct HitPre2 { f2 b, disc; };
 __device__ __forceinline__ HitPre2 intersect_pre2(const f2 cx, const f2 cy, const f2 cz, const f2 r2, float ox,
@@ -401,7 +421,7 @@ __device__ __forceinline__ uint64_t bounce_ns8_v2(const Scene8 &sc, const Tab8 t
     float len2;
     if (MODE == kModeOracle) {                                 // np.linalg.norm, gen_data.py:347: float64 accumulation
         const float p2 = nz * nz;
-        double acc = 0.0 + (double)sq.x;
+        double acc = (double)sq.x;                             // (sdot starts from 0.0: 0 + a square is that square)
         acc = acc + (double)sq.y;
         acc = acc + (double)p2;
         len2 = (float)acc;
@@ -426,16 +446,16 @@ __device__ __forceinline__ uint64_t bounce_ns8_v2(const Scene8 &sc, const Tab8 t
     const float pz = s.dz * uz;
     float dot;
     if (MODE == kModeOracle) {                                 // np.dot, gen_data.py:349
-        double acc = 0.0 + (double)pr.x;
+        double acc = (double)pr.x;                             // (sdot's 0.0 start: twice_canonical() below)
         acc = acc + (double)pr.y;
         acc = acc + (double)pz;
         dot = (float)acc;
     } else {
-        dot = 0.0f + pr.x;                                     // :690 Duplicate(0), :694-696
+        dot = pr.x;                                            // :690 Duplicate(0): twice_canonical() below; :694-696
         dot = dot + pr.y;
         dot = dot + pz;
     }
-    const float k2 = dot * 2.0f;                               // :697
+    const float k2 = twice_canonical(dot);                    // :697
     n.dxy = dxy - uxy * k2;                                    // :699-704
     n.dz = s.dz - uz * k2;
     n.oxy = hxy; n.oz = hz;                                    // :706-708
@@ -475,7 +495,7 @@ __device__ __forceinline__ uint64_t bounce_ns8_v2_hit(const Scene8 &sc, const Ta
     const f2 sq = m.nxy * m.nxy;
     if (MODE == kModeOracle) {                                 // np.linalg.norm, gen_data.py:347: float64 accumulation
         const float p2 = m.nz * m.nz;
-        double acc = 0.0 + (double)sq.x;
+        double acc = (double)sq.x;                             // (sdot starts from 0.0: 0 + a square is that square)
         acc = acc + (double)sq.y;
         acc = acc + (double)p2;
         m.len2 = (float)acc;
@@ -504,16 +524,16 @@ __device__ __forceinline__ void bounce_ns8_v2_reflect(PathState &s, const Bounce
     const float pz = s.dz * uz;
     float dot;
     if (MODE == kModeOracle) {                                 // np.dot, gen_data.py:349
-        double acc = 0.0 + (double)pr.x;
+        double acc = (double)pr.x;                             // (sdot's 0.0 start: twice_canonical() below)
         acc = acc + (double)pr.y;
         acc = acc + (double)pz;
         dot = (float)acc;
     } else {
-        dot = 0.0f + pr.x;                                     // :690 Duplicate(0), :694-696
+        dot = pr.x;                                            // :690 Duplicate(0): twice_canonical() below; :694-696
         dot = dot + pr.y;
         dot = dot + pz;
     }
-    const float k2 = dot * 2.0f;                               // :697
+    const float k2 = twice_canonical(dot);                    // :697
     s.dxy = s.dxy - uxy * k2;                                  // :699-704
     s.dz = s.dz - uz * k2;
     s.oxy = m.hxy; s.oz = m.hz;                                // :706-708
@@ -536,7 +556,7 @@ __device__ __forceinline__ float reflect_packed(const PathState &s, float tmin, 
     float len2;
     if (MODE == kModeOracle) {                                 // np.linalg.norm, gen_data.py:347: float64 accumulation
         const float p2 = nz * nz;
-        double acc = 0.0 + (double)sq.x;
+        double acc = (double)sq.x;                             // (sdot starts from 0.0: 0 + a square is that square)
         acc = acc + (double)sq.y;
         acc = acc + (double)p2;
         len2 = (float)acc;
@@ -561,16 +581,16 @@ __device__ __forceinline__ float reflect_packed(const PathState &s, float tmin, 
     const float pz = s.dz * uz;
     float dot;
     if (MODE == kModeOracle) {                                 // np.dot, gen_data.py:349
-        double acc = 0.0 + (double)pr.x;
+        double acc = (double)pr.x;                             // (sdot's 0.0 start: twice_canonical() below)
         acc = acc + (double)pr.y;
         acc = acc + (double)pz;
         dot = (float)acc;
     } else {
-        dot = 0.0f + pr.x;                                     // :690 Duplicate(0), :694-696
+        dot = pr.x;                                            // :690 Duplicate(0): twice_canonical() below; :694-696
         dot = dot + pr.y;
         dot = dot + pz;
     }
-    const float k2 = dot * 2.0f;                               // :697
+    const float k2 = twice_canonical(dot);                    // :697
     n.dxy = s.dxy - uxy * k2;                                  // :699-704
     n.dz = s.dz - uz * k2;
     n.oxy = hxy; n.oz = hz;                                    // :706-708

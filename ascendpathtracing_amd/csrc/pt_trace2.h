@@ -35,9 +35,10 @@ __device__ __forceinline__ PathState unpack_path(const PathPair &p, int which, u
     return s;
 }
 
-// float32(sum in float64 of three float32 products): np.dot / np.linalg.norm of the NumPy oracle (gen_data.py:347,349)
+// float32(sum in float64 of three float32 products): np.dot / np.linalg.norm of the NumPy oracle (gen_data.py:347,349).  sdot's start
+// value 0.0 is not added: squares are never -0, and the dot product's consumer is twice_canonical() (pt_trace.h).
 __device__ __forceinline__ float sum3_f64(float p0, float p1, float p2) {
-    double acc = 0.0 + (double)p0;
+    double acc = (double)p0;
     acc = acc + (double)p1;
     acc = acc + (double)p2;
     return (float)acc;
@@ -121,12 +122,11 @@ __device__ __forceinline__ void bounce2_ns8(const Scene8 &sc, const Tab8 tab, co
         const f2 p0 = s.dx * ux, p1 = s.dy * uy, p2 = s.dz * uz;
         dot = f2{sum3_f64(p0.x, p1.x, p2.x), sum3_f64(p0.y, p1.y, p2.y)};
     } else {
-        const f2 zero = {0.0f, 0.0f};
-        dot = zero + s.dx * ux;                                                    // :690 Duplicate(0), :694-696
+        dot = s.dx * ux;                                                           // :690 Duplicate(0): twice_canonical() below; :694-696
         dot = dot + s.dy * uy;
         dot = dot + s.dz * uz;
     }
-    const f2 k2 = dot * 2.0f;                                                      // :697
+    const f2 k2 = twice_canonical(dot);                                            // :697
     n.dx = s.dx - ux * k2; n.dy = s.dy - uy * k2; n.dz = s.dz - uz * k2;           // :699-704
     n.ox = hx; n.oy = hy; n.oz = hz;                                               // :706-708
     n.rx = ax * s.rx; n.ry = ay * s.ry; n.rz = az * s.rz;                          // :804-810 (albedo or 1)

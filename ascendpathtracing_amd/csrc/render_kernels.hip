@@ -233,7 +233,12 @@ int do_render_frame(const Launch &ls, const apt_render_params *p, void *stream, 
         // (the walk statistics behind apt_set_trace_counter are a template flag: a frame without a counter does not carry them)
         const bool oracle = p->mode == APT_MODE_ORACLE, stats = ta.traced != nullptr;
         const dim3 qgrid((unsigned)waves), qblock(64);
-#define APT_LAUNCH_GRID_QUEUE(M, R, S) hipLaunchKernelGGL((render_frame_queue8_kernel<M, R, kSceneGrid, S>), qgrid, qblock, qlds, st, spheres, fa, ta, lp, qa)
+        // APT_FLAG_GRID_SLOTS: the caller vouches for the grid (apt_grid_flags): this launch is the frame's only one, and a grid that does not
+        // keep the promise is reported through the status word (grid_walk == 3 tells the kernel to report instead of returning silently)
+        const bool vouched = (p->flags & APT_FLAG_GRID_SLOTS) && eps_allows_rootkey(p->eps);
+        TraceArgs ta_q = ta;
+        ta_q.grid_walk = vouched ? 3u : 0u;
+#define APT_LAUNCH_GRID_QUEUE(M, R, S) hipLaunchKernelGGL((render_frame_queue8_kernel<M, R, kSceneGrid, S>), qgrid, qblock, qlds, st, spheres, fa, ta_q, lp, qa)
         if (oracle) {
             if (rrk) { if (stats) APT_LAUNCH_GRID_QUEUE(kModeOracle, true, true); else APT_LAUNCH_GRID_QUEUE(kModeOracle, true, false); }
             else { if (stats) APT_LAUNCH_GRID_QUEUE(kModeOracle, false, true); else APT_LAUNCH_GRID_QUEUE(kModeOracle, false, false); }
@@ -244,6 +249,7 @@ int do_render_frame(const Launch &ls, const apt_render_params *p, void *stream, 
 #undef APT_LAUNCH_GRID_QUEUE
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return hip_fail(e);
+        if (vouched) return APT_OK;
         ta_frame.grid_walk = 2;
     }
     size_t lds = lp.nleaves > 1 ? (size_t)kMaxStack * 3 * kStackSlots * sizeof(float) : 0;
@@ -350,7 +356,8 @@ int apt_context_check(apt_context *ctx, void *stream) {
     if (bits & APT_DEV_QUEUE_GUARD) what += " queue-loop-bound";
     if (bits & APT_DEV_GRID_TURNS) what += " grid-walk-bound";
     if (bits & APT_DEV_LDS_BASE) what += " lds-base";
-    if (bits & ~(uint32_t)(APT_DEV_QUEUE_GUARD | APT_DEV_GRID_TURNS | APT_DEV_LDS_BASE)) what += " unknown-bits";
+    if (bits & APT_DEV_GRID_MISMATCH) what += " grid-mismatch";
+    if (bits & ~(uint32_t)(APT_DEV_QUEUE_GUARD | APT_DEV_GRID_TURNS | APT_DEV_LDS_BASE | APT_DEV_GRID_MISMATCH)) what += " unknown-bits";
     return fail(APT_ERR_DEVICE, "a kernel reported a failure through the device status word:%s (the frame it wrote is incomplete)", what.c_str());
 }
 

@@ -111,6 +111,19 @@ def build_grid(spheres, num_spheres):
     return buf
 
 
+def grid_flags(grid, num_spheres):
+    """apt_grid_flags: the flags a built grid earns for a scene of `num_spheres` spheres (APT_FLAG_GRID_SLOTS: one launch per
+    frame instead of two) -- `grid` is build_grid()'s numpy buffer or build_grid_device()'s tensor (its 128-byte head is copied
+    to the host: a set-up step, not part of a launch path).  OR the result into RenderParams.flags next to accel."""
+    if hasattr(grid, "data_ptr"):
+        head = grid[:32].cpu().numpy()
+    else:
+        head = np.ascontiguousarray(grid[:32])
+    head = np.ascontiguousarray(head.view(np.uint32))
+    lib().apt_grid_flags.restype = ctypes.c_uint32
+    return int(lib().apt_grid_flags(head.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint32(num_spheres)))
+
+
 def build_grid_device(spheres_dev, num_spheres, stream=None):
     """The same grid built on the GPU from the device-resident table (apt_build_grid_device) -> torch int32 tensor on the
     device (pass its data_ptr() as RenderParams.accel).  Byte-identical to build_grid()."""

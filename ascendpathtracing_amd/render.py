@@ -375,8 +375,12 @@ def render_reference_frame_fused(w, h, s, depth=5, seed=0, spheres=None, mode=No
         if checkpoints is None:
             ck, g_lo = mt_group_checkpoints(w, h, s, seed, pixel_begin, pixel_count, mt_state)
             checkpoints = (torch.from_numpy(ck.view(np.int32)).cuda(), g_lo)
+        else:
+            # a caller's table, made on whatever stream was current then: this launch must come after its upload (ordering) and the
+            # allocator must not recycle it before the launch is through (lifetime) -- both matter when `stream` is a side stream
+            tstream.wait_stream(torch.cuda.current_stream())
         ck_d, g_lo = checkpoints
-        ck_d.record_stream(tstream)              # a caller's table made on another stream: keep it alive for this launch
+        ck_d.record_stream(tstream)
         p = make_params(w, h, s, depth=depth, mode=APT_MODE_ORACLE if mode is None else mode, flags=flags)
         fb = torch.empty((3, pixel_count), dtype=torch.float32, device="cuda")
         u8 = torch.empty((pixel_count, 3), dtype=torch.uint8, device="cuda")

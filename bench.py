@@ -109,7 +109,7 @@ def cpu_baseline(cfg, budget_s=14.0):
                       f"by_threads: the same at 1 and 8 threads on smaller runs"}
 
 
-def quality_check(cfg, fb, u8, pixels=2048):
+def quality_check(cfg, fb, u8, pixels=2048, o_mode=False):
     """BASELINE quality metric on a strided sample of the frame just rendered: per-channel RMS between
     the GPU's and the CPU restatement's float pixel values (after mean + clip, range [0,1]) and the
     number of differing 8-bit PPM values.  Target <= 1e-4; the GPU path is bit-identical, so 0."""
@@ -118,7 +118,7 @@ def quality_check(cfg, fb, u8, pixels=2048):
     W, H, S, D = cfg["w"], cfg["h"], cfg["s"], cfg["depth"]
     fb, u8 = fb.cpu().numpy(), u8.cpu().numpy()
     sph = oracle.gen_spheres()
-    p = oracle.make_params(W, H, S, depth=D, num_spheres=NS, mode=oracle.MODE_K, seed=0)
+    p = oracle.make_params(W, H, S, depth=D, num_spheres=NS, mode=oracle.MODE_O if o_mode else oracle.MODE_K, seed=0)
     run, npix = 16, W * H
     starts = [(k * 2654435761) % (npix - run) for k in range(pixels // run)]
     se, diff = np.zeros(3), 0
@@ -129,7 +129,8 @@ def quality_check(cfg, fb, u8, pixels=2048):
         diff += int((u8[q0:q0 + run] != u8_w).sum())
     n = len(starts) * run
     return {"rms_rgb": [float(x) for x in np.sqrt(se / n)], "differing_ppm_values": diff, "pixels_checked": n,
-            "reference": "oracle C restatement, K-mode", "target_rms": 1e-4}
+            "reference": "oracle C restatement, " + ("O-mode (= the reference's NumPy oracle test_soa, bit for bit on its goldens)" if o_mode else "K-mode"),
+            "target_rms": 1e-4}
 
 
 def gathered_frame_check(full_fb, full_u8, case_names=("C3_bands", "C3_spread", "C3_band5_whole")):
@@ -223,9 +224,10 @@ def extras(torch, apt, render, gen_data, cfg, sph, steps):
         scene4 = torch.from_numpy(gen_data.gen_scene(ns4, seed=1)).cuda()
         grid4 = gen_data.build_grid_device(scene4, ns4)
         torch.cuda.synchronize()
-        p4 = apt.make_params(W, H, S, depth=D, num_spheres=ns4, accel=grid4.data_ptr())
+        # APT_FLAG_GRID_SLOTS (apt_grid_flags reads the built grid's header): ONE launch per frame
+        p4 = apt.make_params(W, H, S, depth=D, num_spheres=ns4, accel=grid4.data_ptr(), flags=gen_data.grid_flags(grid4, ns4))
         ms_full = timed(torch, lambda: render.render_frame(p4, scene4), 2)
-        ms_ret = timed(torch, lambda: render.render_frame(p4.copy(flags=apt.APT_FLAG_RETIRE), scene4), 2)
+        ms_ret = timed(torch, lambda: render.render_frame(p4.copy(flags=p4.flags | apt.APT_FLAG_RETIRE), scene4), 2)
         # walk statistics from a separate, untimed launch at 64 spp (the counting instantiation of the kernel; per-segment averages do
         # not depend on the sample count): cells visited and candidates tested per traced segment -> the EXECUTED work of a culled
         # traversal, 20 flops per candidate test + 33 per segment (SURVEY 8(d)'s per-pair / per-segment counts), against the vector peak
@@ -300,6 +302,77 @@ def dry_run(args):
         dist.destroy_process_group()
 
 
+HEADLINE_KERNEL = "render_frame_kernel<0, 0, 8, false, true>"      # K-mode, 8-sphere scene, 8 lanes per sub-pixel, no retirement, two paths per lane
+
+
+def traffic_probe():
+    """`bench.py --traffic-probe`: what measure_traffic() wraps in rocprofv3 -- the headline launch (C2, K-mode, every segment traced)
+    a few times, nothing else (no oracle, no timing, no output)."""
+    import __graft_entry__
+    __graft_entry__.build()
+    import torch
+    import ascendpathtracing_amd as apt
+    from ascendpathtracing_amd import gen_data, render
+    apt._lib.require_gpu()
+    p = apt.make_params(C2["w"], C2["h"], C2["s"], depth=C2["depth"], num_spheres=NS, mode=apt.APT_MODE_KERNEL, seed=0)
+    sph = torch.from_numpy(gen_data.gen_spheres()).cuda()
+    fb = torch.empty((3, C2["w"] * C2["h"]), dtype=torch.float32, device="cuda")
+    u8 = torch.empty((C2["w"] * C2["h"], 3), dtype=torch.uint8, device="cuda")
+    for _ in range(5):
+        render.render_frame(p, sph, fb=fb, fb_u8=u8)
+    torch.cuda.synchronize()
+
+
+def measure_traffic(timeout_s=300):
+    """roofline.traffic measured IN THIS RUN (it used to be replayed from a committed file): HBM bytes per launch of the
+    headline kernel from two rocprofv3 passes -- `--pmc FETCH_SIZE` and `--pmc WRITE_SIZE`, each with --kernel-trace only, as
+    MI355X_MICROARCH.md's HBM section prescribes (separate passes; values in KiB; FETCH_SIZE doubled on gfx950) -- of
+    `python3 bench.py --traffic-probe`, run as CHILD processes before this process has touched the GPU (bench.py cannot wrap itself).
+    -> dict for the roofline block, or {"error": ...} (no rocprofv3, a pass failed, already under a profiler): the caller then falls
+    back to the committed figure of this very build, or null."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+        return {"error": "this process runs under a profiler already"}
+    tool = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if tool is None:
+        return {"error": "rocprofv3 not found"}
+    res, tmp = {}, tempfile.mkdtemp(prefix="apt_traffic_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, ctr)
+            cmd = [tool, "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", out, "--",
+                   sys.executable, os.path.abspath(__file__), "--traffic-probe"]
+            r = subprocess.run(cmd, env=env, cwd="/tmp", stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=timeout_s)
+            if r.returncode != 0:
+                return {"error": f"rocprofv3 --pmc {ctr} exited {r.returncode}: {r.stderr.decode(errors='replace')[-200:]}"}
+            vals, dur = [], []
+            for f in glob.glob(os.path.join(out, "**", "*_counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if HEADLINE_KERNEL in row["Kernel_Name"] and row["Counter_Name"] == ctr:
+                        vals.append(float(row["Counter_Value"]))
+            for f in glob.glob(os.path.join(out, "**", "*_kernel_trace.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if HEADLINE_KERNEL in row["Kernel_Name"]:
+                        dur.append(float(row["End_Timestamp"]) - float(row["Start_Timestamp"]))
+            if not vals:
+                return {"error": f"no {ctr} rows for {HEADLINE_KERNEL}"}
+            res[ctr] = (sum(vals) / len(vals) * 1024.0, len(vals), sum(dur) / max(1, len(dur)) / 1e6)
+    except (OSError, subprocess.SubprocessError, KeyError, ValueError) as e:
+        return {"error": repr(e)[:200]}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    fetch, write = 2.0 * res["FETCH_SIZE"][0], res["WRITE_SIZE"][0]
+    return {"traffic": round(fetch + write), "traffic_fetch_bytes_x2": round(fetch), "traffic_write_bytes": round(write),
+            "traffic_launches_averaged": res["WRITE_SIZE"][1], "traffic_probe_kernel_ms": round(res["WRITE_SIZE"][2], 3),
+            "traffic_source": "measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, KiB, "
+                              "FETCH_SIZE x2 on gfx950) of `bench.py --traffic-probe` as child processes"}
+
+
 def self_launch(n):
     """`python bench.py --gpus N` typed as is (no torchrun): one process per GPU, started as a CHILD process before this one has
     touched the GPU (nothing here imports torch; a process that has initialised HIP must never exec another program on this pool),
@@ -329,6 +402,8 @@ def main():
     ap.add_argument("--stripes", type=int, default=1, help="interleaved stripes per rank (N > 1; see dist.py)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
+    ap.add_argument("--no-traffic-probe", action="store_true", help="do not measure roofline.traffic with rocprofv3 child processes (N = 1)")
+    ap.add_argument("--traffic-probe", action="store_true", help="internal: the launches measure_traffic() profiles")
     ap.add_argument("--dry-run", action="store_true",
                     help="control-flow rehearsal without a GPU (tests/test_bench_dry_run.py): gloo, CPU tensors, a tiny frame and NO "
                          "render at all (the launch is a no-op) -- exercises the rendezvous, sharding, double-buffered gather, "
@@ -338,6 +413,11 @@ def main():
         return self_launch(args.gpus)         # plain `python bench.py --gpus N`: start the N ranks ourselves
     if args.dry_run:
         return dry_run(args)
+    if args.traffic_probe:
+        return traffic_probe()
+    live = None
+    if args.gpus == 1 and "WORLD_SIZE" not in os.environ and args.workload in ("auto", "c2") and not args.no_traffic_probe:
+        live = measure_traffic()              # child processes; this process has not touched the GPU yet
 
     import __graft_entry__
     __graft_entry__.build()                   # incremental, serialised by a file lock; does not touch the GPU
@@ -430,6 +510,14 @@ def main():
         build_id = None
     if workload != "c2" or world != 1:
         traffic, traffic_tag = None, None     # the committed PMC passes are of the N = 1 C2 launch
+    traffic_extra = {}
+    if live is not None and "traffic" in live:   # measured in this very run: that is the figure
+        traffic, traffic_tag = live["traffic"], None
+        traffic_extra = {k: v for k, v in live.items() if k != "traffic"}
+        traffic_extra["traffic_over_algorithmic"] = round(live["traffic"] / (W * H * 15 + 512), 4)
+    elif live is not None:
+        traffic_extra = {"traffic_probe_error": live.get("error"),
+                         "traffic_source": "profiles/hbm_traffic.json (committed PMC passes of this build)" if traffic is not None else None}
     names = {"c2": f"C2: gen_spheres() 8-sphere scene, {W}x{H}, S={S} ({4 * S} spp), depth {D}",
              "c3": f"C3: gen_spheres() 8-sphere scene, {W}x{H}, S={S} ({4 * S} spp), depth {D}, strong-sharded over {world} rank(s): "
                    f"contiguous pixel bands (dist.split_range), {shard.pixel_count} pixels per rank",
@@ -455,7 +543,8 @@ def main():
                      # coordinate have in common and that the kernel evaluates once
                      "flops_per_segment_executed": 163,   # holds for the gen_spheres() table (its equality pattern), which every workload here renders
                      "frac_of_peak_by_executed_flops": round(achieved * 163.0 / flops_per_segment(NS) / PEAK_FP32_TFLOPS, 4),
-                     "traffic": traffic, "traffic_recorded_for_build": traffic_tag, "build_id": build_id},
+                     "traffic": traffic, "algorithmic_bytes": shard.pixel_count * 15 + 512, **traffic_extra,
+                     "traffic_recorded_for_build": traffic_tag, "build_id": build_id},
         "target_mray_per_gpu": 100.0,
     }
     if world > 1:       # what the first hardware run needs in order to explain itself: the collective's library, who can reach whom
@@ -487,6 +576,26 @@ def main():
             fbv, u8v = slots[(args.steps - 1) % 2][0]
             out["quality"] = quality_check(cfg, fbv, u8v)
             out["cpu_baseline"] = cpu_baseline(cfg)
+        if workload == "c2":
+            # The SAME workload in the arithmetic the reference pins at every depth: O-mode = scripts/gen_data.py:246-429
+            # test_soa, whose two shading dot products accumulate float32 products in float64 (np.linalg.norm / np.dot, :347,:349).  K-mode
+            # (the Ascend kernel's all-fp32 order, what `value` is quoted on) is only pinned by the reference up to depth 2.  Own kernel
+            # timing (HIP events), own roofline fraction, own quality check against the oracle in THAT mode.
+            po = apt.make_params(W, H, S, depth=D, num_spheres=NS, mode=apt.APT_MODE_ORACLE, seed=0)
+            fbo = torch.empty((3, W * H), dtype=torch.float32, device="cuda")
+            u8o = torch.empty((W * H, 3), dtype=torch.uint8, device="cuda")
+            o_ms = timed(torch, lambda: render.render_frame(po, sph, fb=fbo, fb_u8=u8o), args.steps)
+            o_ach = seg_total * flops_per_segment(NS) / (o_ms * 1e-3) / 1e12
+            out["roofline_o_mode"] = {"bound": "valu", "kernel": "render_frame_kernel<O,ns8,group8>", "kernel_ms": round(o_ms, 3),
+                                      "value_mray_per_s": round(seg_total / o_ms / 1e3, 1), "achieved": round(o_ach, 3), "peak": PEAK_FP32_TFLOPS,
+                                      "unit": "TFLOP/s", "frac": round(o_ach / PEAK_FP32_TFLOPS, 4),
+                                      "frac_of_nofma_peak": round(o_ach / PEAK_NOFMA_TOPS, 4), "flops_per_segment": flops_per_segment(NS),
+                                      "over_k_mode": round(o_ms / kern_ms, 4),
+                                      "arithmetic": "scripts/gen_data.py test_soa: float64-accumulated norm and dot (12 more issue slots per path and bounce "
+                                                    "than the packed fp32 sums: 6 conversions + 4 float64 adds per dot product instead of one packed add per path)"}
+            if not args.no_cpu_baseline:
+                out["roofline_o_mode"]["quality"] = quality_check(cfg, fbo, u8o, o_mode=True)
+            del fbo, u8o
         if not args.no_extra and workload == "c2":
             out["extra"] = extras(torch, apt, render, gen_data, cfg, sph, max(3, args.steps // 2))
     if os.environ.get("APT_BENCH_SHARE_GPU") == "1":

@@ -80,6 +80,12 @@ enum {
     APT_FLAG_EMISSION = 4u,/* colour = throughput * emission(light sphere) per channel       */
                            /* (spheres.bin planes 4..6) instead of the literal gain 12 of      */
                            /* render.cpp:194-196; identical on the reference scene (em = 12).  */
+    APT_FLAG_GRID_SLOTS = 16u, /* render_frame with `accel`: the CALLER states that the grid at `accel` was built for this scene and    */
+                           /* carries the pair-slot tables (apt_grid_flags() says so for a built grid).  The frame then takes ONE     */
+                           /* launch -- the sample-queue kernel's grid form -- instead of two (without the flag both frame kernels are  */
+                           /* launched and the grid's own header decides ON THE DEVICE which one renders; the other returns at once).   */
+                           /* A grid that does not keep the promise is not walked: the kernel renders nothing and reports              */
+                           /* APT_DEV_GRID_MISMATCH through the device status word.  Same image either way.                            */
     APT_FLAG_RR = 2u       /* EXTENSION (not in the reference; BASELINE config 5): Russian */
                            /* roulette.  After shading bounce d (0-based) with d+1 >=       */
                            /* rr_start, a path that is alive with q = max(r,g,b) > 0        */
@@ -176,7 +182,8 @@ int  apt_context_set_refill_lanes(apt_context *ctx, uint32_t lanes);
 enum {
     APT_DEV_QUEUE_GUARD = 1u,  /* sample-queue kernel (APT_FLAG_RETIRE, 8 spheres): the bound on a wave's loop turns ran out      */
     APT_DEV_GRID_TURNS = 2u,   /* sample-queue kernel, grid form: the bound on a wave's walk turns ran out                         */
-    APT_DEV_LDS_BASE = 4u      /* sample-queue kernels: the dynamic LDS region does not start at LDS address 0 (a build problem)    */
+    APT_DEV_LDS_BASE = 4u,     /* sample-queue kernels: the dynamic LDS region does not start at LDS address 0 (a build problem)    */
+    APT_DEV_GRID_MISMATCH = 8u /* APT_FLAG_GRID_SLOTS: the grid at `accel` is not this scene's or has no pair-slot tables           */
 };
 int  apt_context_check(apt_context *ctx, void *stream);
 int  apt_check(void *stream);
@@ -327,6 +334,11 @@ int apt_gen_scene_host(uint32_t num_spheres, uint64_t seed, float *spheres,
  * cell) for the frame kernel's per-lane walk; apt_render_frame picks the kernel from what the buffer carries,
  * on the device. */
 int apt_build_grid_host(const float *spheres_host, uint32_t num_spheres, void *grid, size_t *out_bytes);
+
+/* The flags a built grid earns for a scene of `num_spheres` spheres, from the first 128 bytes of the buffer (HOST memory: the
+ * buffer apt_build_grid_host filled, or a copy of the head of a device-built one): APT_FLAG_GRID_SLOTS when it is a grid for that
+ * sphere count with pair-slot tables, else 0.  OR the result into apt_render_params.flags next to `accel`. */
+uint32_t apt_grid_flags(const void *grid_head_host, uint32_t num_spheres);
 
 /* The same grid built ON THE DEVICE from the [10][Ns] table in device memory: byte-identical to what
  * apt_build_grid_host writes for that scene (radix-select median, scans and atomics in kernels; the scalar header

@@ -122,7 +122,7 @@ t0 = time.time()
 grid = torch.from_numpy(gen_data.build_grid(scene.cpu().numpy(), 10000).view("int32")).cuda()
 t_grid = time.time() - t0
 for flags, name in ((0, ""), (apt.APT_FLAG_RETIRE, " retire")):
-    p = apt.make_params(1920, 1080, 64, depth=8, num_spheres=10000, flags=flags, accel=grid.data_ptr())
+    p = apt.make_params(1920, 1080, 64, depth=8, num_spheres=10000, flags=flags | gen_data.grid_flags(grid, 10000), accel=grid.data_ptr())
     ms = timeit(lambda: render.render_frame(p, scene), 2)
     report(f"C4 10k spheres 1080p 256spp D8 grid traversal{name}", ms, p.num_paths * 8, 10000,
            {"grid_build_host_seconds": round(t_grid, 3), "grid_bytes": int(grid.numel() * 4)}, culled=True)

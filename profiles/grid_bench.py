@@ -33,7 +33,7 @@ dgrid = gen_data.build_grid_device(scene, args.ns); torch.cuda.synchronize()
 t_dev = time.time() - t0
 assert torch.equal(dgrid, grid)
 p = apt.make_params(1920, 1080, args.s, depth=args.depth, num_spheres=args.ns, accel=grid.data_ptr(),
-                    flags=apt.APT_FLAG_RETIRE if args.retire else 0)
+                    flags=(apt.APT_FLAG_RETIRE if args.retire else 0) | gen_data.grid_flags(grid, args.ns))
 fb, u8 = render.render_frame(p, scene)
 torch.cuda.synchronize()
 best = 1e9

@@ -9,7 +9,7 @@ OUT=gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd "$(dirname "$0")/.." || exit 1
 export TMPDIR=/tmp
-CMD="python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extra"
+CMD="python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extra --no-traffic-probe"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- $CMD > "$OUT/trace.log" 2>&1 || echo "trace pass failed"
 rocprofv3 -L > "$OUT/counters_available.txt" 2>&1 || true
 i=0

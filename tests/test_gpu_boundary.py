@@ -178,7 +178,7 @@ def test_host_pointer_entry_accepts_the_whole_range_and_rejects_strict_sub_range
         apt.render.set_default_params(apt.default_params())
 
 
-def test_debug_knobs_are_context_state_not_environment(apt, oracle):
+def test_debug_knobs_are_context_state_not_environment(apt, oracle, monkeypatch):
     """kernels are selected through apt_context_set_debug, per context; nothing in a launch path reads the
     process environment.  Unknown keys and out-of-range values are APT_ERR_ARG; a knob set on one context does not leak into
     another (ppw = 1 on a private context gives the same frame and its own wave split)."""
@@ -191,12 +191,10 @@ def test_debug_knobs_are_context_state_not_environment(apt, oracle):
         apt.render.set_debug("queue_nbuf", 1)
     sph = dev(oracle.gen_spheres())
     p = apt.make_params(24, 10, 16, depth=8, flags=apt.APT_FLAG_RETIRE, seed=3)
-    os.environ["APT_QUEUE_PPW"] = "1"               # the default context exists already: the environment is not consulted again
-    try:
-        with apt.render.TraceCounter() as t_def:
-            ref, ref8 = apt.render.render_frame(p, sph)
-    finally:
-        os.environ.pop("APT_QUEUE_PPW")
+    monkeypatch.setenv("APT_QUEUE_PPW", "1")        # the default context exists already: the environment is not consulted again
+    with apt.render.TraceCounter() as t_def:
+        ref, ref8 = apt.render.render_frame(p, sph)
+    monkeypatch.delenv("APT_QUEUE_PPW")
     ctx = apt.render.Context()
     ctx.set_debug("queue_ppw", 1)
     counter = torch.zeros(4, dtype=torch.int64, device="cuda")
@@ -329,7 +327,7 @@ def _nccl_pipeline_worker(rank, world, port, out_path, frames):
     import sys
     from conftest import ROOT
     sys.path.insert(0, ROOT)
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")   # (a spawned child: its own environment)
     import torch.distributed as dist
     torch.cuda.set_device(rank)
     dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
