@@ -61,7 +61,7 @@ __global__ __launch_bounds__(kBlock, APT_TWO_WAVES) void render_frame_mt_kernel(
     const bool planes = sc.planes;
     const Gain3 gain = load_gain(sph, ta);
     const uint32_t S = 1u << ma.log2_s, H = fa.height;
-    const uint32_t blk = xcd_contiguous_block(blockIdx.x, gridDim.x);   // (XCD-aware: neighbouring pixel groups through one L2)
+    const uint32_t blk = xcd_chunked_block<2>(blockIdx.x, gridDim.x);   // (XCD-aware: neighbouring pixel groups through one L2)
     const uint64_t group = ma.first_group + blk;
     const uint32_t npaths = 312u * S;                           // of this group
     const uint64_t q0 = group * kMtGroupPixels;                 // first pixel
@@ -195,7 +195,7 @@ __global__ __launch_bounds__(kBlock, APT_TWO_WAVES) void render_frame_mt_any_ker
     const bool planes = sc.planes;
     const Gain3 gain = load_gain(sph, ta);
     const uint32_t S = fa.samples, H = fa.height, nleaves = lp.nleaves;
-    const uint32_t blk = xcd_contiguous_block(blockIdx.x, gridDim.x);   // (XCD-aware: neighbouring pixel groups through one L2)
+    const uint32_t blk = xcd_chunked_block<2>(blockIdx.x, gridDim.x);   // (XCD-aware: neighbouring pixel groups through one L2)
     const uint64_t group = ma.first_group + blk;
     const uint32_t npaths = 312u * S;                           // of this group
     const uint64_t q0 = group * kMtGroupPixels;                 // first pixel

@@ -184,7 +184,7 @@ __global__ __launch_bounds__(kBlock, TWO ? APT_TWO_WAVES : (SC == kSceneGrid ? A
     (void)planes;
 
     const uint32_t lane = threadIdx.x & 63;
-    const uint64_t L = (uint64_t)xcd_contiguous_block(blockIdx.x, gridDim.x) * kBlock + threadIdx.x;
+    const uint64_t L = (uint64_t)xcd_chunked_block<16>(blockIdx.x, gridDim.x) * kBlock + threadIdx.x;
     const uint32_t j = (GROUP == 8) ? (uint32_t)(L & 7) : 0u;
     const uint32_t sub = (uint32_t)(L / GROUP) & 3u;
     const uint64_t pl = L / (4 * GROUP);

@@ -114,7 +114,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SC == kScene
     // descriptor's group_segment_fixed_size); a build that breaks this renders nothing rather than reading the wrong pool entries.
     if ((uint32_t)(uintptr_t)qlds != 0u) { report_status(ta, APT_DEV_LDS_BASE); return; }
     if (SC == kSceneGrid && !grid_queue_usable(ta)) {                  // wave-uniform: render_frame_kernel renders this frame (its grid_walk == 2) --
+#ifndef APT_NO_GRID_ASSERT   // A/B builds only
         if (ta.grid_walk == 3u) report_status(ta, APT_DEV_GRID_MISMATCH);   // or, under APT_FLAG_GRID_SLOTS, nobody does: the caller's promise did not hold
+#endif
         return;
     }
     if (lane == 0) cam = camera_lite(fa.cam);
@@ -138,7 +140,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SC == kScene
     __syncthreads();
 
     // this wave's pixels
-    const uint64_t wb = (uint64_t)xcd_contiguous_block(blockIdx.x, gridDim.x) * qa.ppw;   // (XCD-aware: neighbouring pixels through one L2)
+#ifdef APT_QUEUE_NO_XCD   // A/B builds only
+    const uint64_t wb = (uint64_t)blockIdx.x * qa.ppw;
+#else
+    const uint64_t wb = (uint64_t)xcd_chunked_block<8>(blockIdx.x, gridDim.x) * qa.ppw;   // (XCD-aware: neighbouring pixels through one L2)
+#endif
     const uint32_t npx = (uint32_t)min((uint64_t)qa.ppw, fa.pixel_count - wb);
     const uint32_t U = npx * nleaves;                                   // units of this wave
     const uint64_t q0 = fa.pixel_begin + wb;

@@ -78,13 +78,20 @@ struct TraceArgs {
 // Workgroup id -> the block of work it takes, XCD-aware.  The dispatcher hands consecutive workgroup ids to the 8 XCDs of an MI355X in turn,
 // and each XCD has its own L2: with the identity mapping the workgroups that write one 128-byte line of the frame (32 float pixels of a plane,
 // 42 u8 pixels) sit on different XCDs, every L2 holds -- and writes back -- a PART of the line, and HBM saw 1.32x the frame's bytes (round 4:
-// 40.9 MB written for 31.1).  Here XCD x takes the x-th CONTIGUOUS eighth of the blocks, in order, so neighbouring pixels are written
-// through one L2 at about the same time and leave it as whole lines.  Pure relabelling of independent blocks: no effect on any result.
-__device__ __forceinline__ uint32_t xcd_contiguous_block(uint32_t wg, uint32_t nwg) {
-    constexpr uint32_t kXcds = 8;
-    const uint32_t xcd = wg % kXcds, idx = wg / kXcds;
-    const uint32_t q = nwg / kXcds, r = nwg % kXcds;
-    return xcd * q + (xcd < r ? xcd : r) + idx;        // (idx < q + (xcd < r) for every wg < nwg)
+// 40.9 MB written for 31.1).  Here the blocks are taken in chunks of 8 * K: within a chunk XCD x takes K CONSECUTIVE blocks (its j-th workgroup of
+// the chunk takes block x * K + j), so neighbouring pixels are written through one L2 at about the same time and leave it as whole lines, while
+// every XCD still works on an interleaved 1/8 sample of the whole frame.  (The first form gave XCD x the x-th contiguous EIGHTH of the frame: same
+// traffic, but where the cost per pixel varies over the image -- retirement, roulette, the grid scenes -- the XCDs then finish far apart: C2 with
+// retirement 15.7 -> 18.3 ms, depth 32 33.3 -> 42.4, C4 +29 %; profiles/r05_variants_xcd_mapping.jsonl.)  The last, partial chunk keeps the
+// identity.  Pure relabelling of independent blocks: no effect on any result.
+template <uint32_t K>
+__device__ __forceinline__ uint32_t xcd_chunked_block(uint32_t wg, uint32_t nwg) {
+    constexpr uint32_t kXcds = 8, G = kXcds * K;
+    static_assert((K & (K - 1)) == 0, "shifts and masks");
+    const uint32_t full = nwg & ~(G - 1u);
+    if (wg >= full) return wg;
+    const uint32_t r = wg & (G - 1u);
+    return (wg & ~(G - 1u)) + (r & (kXcds - 1u)) * K + r / kXcds;
 }
 
 // A kernel that has to give up says so (the reference asserts inside its kernel: src/render.cpp:68-73): one lane ORs the bit into the
@@ -103,8 +110,13 @@ __device__ __forceinline__ void report_status(const TraceArgs &ta, uint32_t bit)
 // all three products are -0: the sum is then +0 with it and -0 without.  The one consumer is k2 = dot * 2 (:697), and fma(dot, 2, +0)
 // is that product exactly (a doubling never rounds; overflow and NaN go the same way) with -0 turned into +0 by the addend: the start
 // value's whole effect for the price of the multiply itself.  (The norm's products are squares, never -0: nothing to preserve there.)
+#ifdef APT_NO_TWICE_CANON   // A/B builds only (timing: not bit-exact for an all -0 dot product)
+__device__ __forceinline__ float twice_canonical(float dot) { return dot * 2.0f; }
+__device__ __forceinline__ f2 twice_canonical(f2 dot) { return dot * 2.0f; }
+#else
 __device__ __forceinline__ float twice_canonical(float dot) { return __builtin_fmaf(dot, 2.0f, 0.0f); }
 __device__ __forceinline__ f2 twice_canonical(f2 dot) { return __builtin_elementwise_fma(dot, f2{2.0f, 2.0f}, f2{0.0f, 0.0f}); }
+#endif
 
 struct HitPre2 { f2 b, disc; };
 __device__ __forceinline__ HitPre2 intersect_pre2(const f2 cx, const f2 cy, const f2 cz, const f2 r2, float ox,
