@@ -591,8 +591,8 @@ def main():
                                       "unit": "TFLOP/s", "frac": round(o_ach / PEAK_FP32_TFLOPS, 4),
                                       "frac_of_nofma_peak": round(o_ach / PEAK_NOFMA_TOPS, 4), "flops_per_segment": flops_per_segment(NS),
                                       "over_k_mode": round(o_ms / kern_ms, 4),
-                                      "arithmetic": "scripts/gen_data.py test_soa: float64-accumulated norm and dot (12 more issue slots per path and bounce "
-                                                    "than the packed fp32 sums: 6 conversions + 4 float64 adds per dot product instead of one packed add per path)"}
+                                      "arithmetic": "scripts/gen_data.py test_soa: float64-accumulated norm and dot (10 more issue slots per path and bounce "
+                                                    "than the packed fp32 sums: 3 v_cvt_f64_f32 + 2 v_add_f64 + 1 v_cvt_f32_f64 per dot product and path instead of one packed add)"}
             if not args.no_cpu_baseline:
                 out["roofline_o_mode"]["quality"] = quality_check(cfg, fbo, u8o, o_mode=True)
             del fbo, u8o
