@@ -323,7 +323,7 @@ def traffic_probe():
     torch.cuda.synchronize()
 
 
-def measure_traffic(timeout_s=300):
+def measure_traffic(timeout_s=150):
     """roofline.traffic measured IN THIS RUN (it used to be replayed from a committed file): HBM bytes per launch of the
     headline kernel from two rocprofv3 passes -- `--pmc FETCH_SIZE` and `--pmc WRITE_SIZE`, each with --kernel-trace only, as
     MI355X_MICROARCH.md's HBM section prescribes (separate passes; values in KiB; FETCH_SIZE doubled on gfx950) -- of

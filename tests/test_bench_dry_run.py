@@ -62,3 +62,49 @@ def test_plain_bench_gpus_n_launches_its_own_ranks(n):
     assert len(lines) == 1, r.stdout
     out = json.loads(lines[0])
     assert out["dry_run"] is True and out["n_gpus"] == n and out["gathered_frame_complete"] is True and out["scaling"] == "strong"
+
+
+def _fake_rocprofv3(tmp_path, body):
+    tool = tmp_path / "rocprofv3"
+    tool.write_text("#!/usr/bin/env python3\n" + body)
+    tool.chmod(0o755)
+    return str(tmp_path)
+
+
+def test_live_traffic_probe_parses_rocprofv3_output_and_degrades_gracefully(tmp_path, monkeypatch):
+    """bench.py measures roofline.traffic in the same run by wrapping `bench.py --traffic-probe` in two rocprofv3
+    counter passes.  Here rocprofv3 is a stand-in script (no GPU): the KiB -> bytes conversion, the gfx950 doubling of FETCH_SIZE,
+    the kernel filter and the averaging are checked on known numbers; a failing profiler, a missing one and a run that is already
+    being profiled give {"error": ...} (bench.py then falls back to the committed figure of the same build, or null) -- never an exception."""
+    import bench
+    for k in [k for k in os.environ if k.startswith(("ROCPROF", "ROCP_"))]:
+        monkeypatch.delenv(k)
+    body = r'''
+import os, sys
+a = sys.argv
+out, ctr = a[a.index("-d") + 1], a[a.index("--pmc") + 1]
+assert "--kernel-trace" in a and a[a.index("--") + 1:][1].endswith("bench.py") and a[-1] == "--traffic-probe"
+os.makedirs(out + "/host/", exist_ok=True)
+k = "void (anonymous namespace)::render_frame_kernel<0, 0, 8, false, true>(float const*, ...)"
+other = "void (anonymous namespace)::render_frame_kernel<1, 0, 8, false, true>(float const*, ...)"
+vals = {"FETCH_SIZE": [400.0, 600.0], "WRITE_SIZE": [30000.0, 31000.0]}[ctr]
+with open(out + "/host/1_counter_collection.csv", "w") as f:
+    f.write("Kernel_Name,Counter_Name,Counter_Value\n")
+    for v in vals: f.write('"%s",%s,%f\n' % (k, ctr, v))
+    f.write('"%s",%s,%f\n' % (other, ctr, 1e9))
+with open(out + "/host/1_kernel_trace.csv", "w") as f:
+    f.write("Kernel_Name,Start_Timestamp,End_Timestamp\n")
+    f.write('"%s",1000,20001000\n"%s",0,5\n' % (k, other))
+'''
+    monkeypatch.setenv("PATH", _fake_rocprofv3(tmp_path, body) + os.pathsep + os.environ["PATH"])
+    r = bench.measure_traffic(timeout_s=60)
+    assert r["traffic_fetch_bytes_x2"] == 2 * 500 * 1024 and r["traffic_write_bytes"] == 30500 * 1024
+    assert r["traffic"] == r["traffic_fetch_bytes_x2"] + r["traffic_write_bytes"] and r["traffic_launches_averaged"] == 2
+    assert r["traffic_probe_kernel_ms"] == 20.0 and "measured in this run" in r["traffic_source"]
+    bad = tmp_path / "bad"
+    bad.mkdir()
+    monkeypatch.setenv("PATH", _fake_rocprofv3(bad, "import sys\nsys.stderr.write('no device')\nsys.exit(3)\n") + os.pathsep + os.environ["PATH"])
+    r = bench.measure_traffic(timeout_s=60)
+    assert "exited 3" in r["error"] and "traffic" not in r
+    monkeypatch.setenv("ROCPROFILER_SOMETHING", "1")          # already under a profiler: no nested run
+    assert "profiler" in bench.measure_traffic()["error"]
