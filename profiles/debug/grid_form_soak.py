@@ -51,7 +51,9 @@ for it in range(args.n):
     with render.TraceCounter() as tb:
         fb_b, u8_b = render.render_frame(p, d_scene)
     with render.TraceCounter() as tq:
-        fb_q, u8_q = render.render_frame(p.copy(accel=grid.data_ptr()), d_scene)
+        # every other scene with APT_FLAG_GRID_SLOTS (round 5: the frame is then ONE launch, the grid form alone)
+        vouch = gen_data.grid_flags(grid, ns) if it % 2 else 0
+        fb_q, u8_q = render.render_frame(p.copy(accel=grid.data_ptr(), flags=flags | vouch), d_scene)
     torch.cuda.synchronize()
     ok = bool(torch.equal(fb_q.view(torch.int32), fb_b.view(torch.int32)) and torch.equal(u8_q, u8_b) and tq.value == tb.value)
     if not ok:
