@@ -41,7 +41,8 @@ for it in range(args.n):
         tab[0:4, b] = tab[0:4, a]
         tab[1, b] = 100.0 - tab[1, a]
     d_scene = torch.from_numpy(scene).cuda()
-    grid = torch.from_numpy(gen_data.build_grid(scene, ns).view(np.int32)).cuda()
+    hgrid = gen_data.build_grid(scene, ns)
+    grid = torch.from_numpy(hgrid.view(np.int32)).cuda()
     w, h = int(rng.randint(3, 20)), int(rng.randint(2, 14))
     s_ = int(rng.choice([8, 9, 16, 20, 33, 64, 136]))
     depth = int(rng.choice([1, 2, 5, 8, 12]))
@@ -52,7 +53,7 @@ for it in range(args.n):
         fb_b, u8_b = render.render_frame(p, d_scene)
     with render.TraceCounter() as tq:
         # every other scene with APT_FLAG_GRID_SLOTS (round 5: the frame is then ONE launch, the grid form alone)
-        vouch = gen_data.grid_flags(grid, ns) if it % 2 else 0
+        vouch = gen_data.grid_flags(hgrid, ns) if it % 2 else 0
         fb_q, u8_q = render.render_frame(p.copy(accel=grid.data_ptr(), flags=flags | vouch), d_scene)
     torch.cuda.synchronize()
     ok = bool(torch.equal(fb_q.view(torch.int32), fb_b.view(torch.int32)) and torch.equal(u8_q, u8_b) and tq.value == tb.value)
