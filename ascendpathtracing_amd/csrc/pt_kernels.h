@@ -419,8 +419,9 @@ __global__ __launch_bounds__(kBlock, TWO ? APT_TWO_WAVES : (SC == kSceneGrid ? A
 
     // decode_color: data_visualization.py:36-57
     // The 8-bit pixels of a workgroup (kBlock / (4 * GROUP) consecutive pixels, 3 bytes each: a whole number of dwords that starts on a
-    // dword when the image does) leave as DWORD stores assembled in LDS: three byte stores per pixel from different waves made the L2
-    // read-modify-write partial dwords (round 4: 5.3 MB fetched and 1.32x the frame's bytes written per C2 launch for 31.1 MB of output).
+    // dword when the image does) leave as DWORD stores assembled in LDS instead of three byte stores per pixel from different waves: no partial
+    // dwords for the L2 to merge.  (Measured: what brought the frame's write traffic to exactly its size was the XCD-aware block mapping,
+    // pt_trace.h; this took the launch's fetched bytes from 0.88 to 0.83 MB.  Kept: it costs one barrier per workgroup.)
     constexpr uint32_t kPixPerBlock = kBlock / (4 * GROUP), kU8Words = kPixPerBlock * 3 / 4;
     static_assert(kPixPerBlock * 3 % 4 == 0, "a workgroup's 8-bit pixels are whole dwords");
     __shared__ uint32_t u8pack[kU8Words];

@@ -77,13 +77,14 @@ struct TraceArgs {
 };
 // Workgroup id -> the block of work it takes, XCD-aware.  The dispatcher hands consecutive workgroup ids to the 8 XCDs of an MI355X in turn,
 // and each XCD has its own L2: with the identity mapping the workgroups that write one 128-byte line of the frame (32 float pixels of a plane,
-// 42 u8 pixels) sit on different XCDs, every L2 holds -- and writes back -- a PART of the line, and HBM saw 1.32x the frame's bytes (round 4:
-// 40.9 MB written for 31.1).  Here the blocks are taken in chunks of 8 * K: within a chunk XCD x takes K CONSECUTIVE blocks (its j-th workgroup of
-// the chunk takes block x * K + j), so neighbouring pixels are written through one L2 at about the same time and leave it as whole lines, while
-// every XCD still works on an interleaved 1/8 sample of the whole frame.  (The first form gave XCD x the x-th contiguous EIGHTH of the frame: same
-// traffic, but where the cost per pixel varies over the image -- retirement, roulette, the grid scenes -- the XCDs then finish far apart: C2 with
-// retirement 15.7 -> 18.3 ms, depth 32 33.3 -> 42.4, C4 +29 %; profiles/r05_variants_xcd_mapping.jsonl.)  The last, partial chunk keeps the
-// identity.  Pure relabelling of independent blocks: no effect on any result.
+// 42 u8 pixels) sit on different XCDs, every L2 holds -- and writes back -- a PART of the line, and the fabric saw 1.20x the frame's bytes
+// (rounds 2-4: 37.3 MB written per C2 launch for 31.1, steady state).  Here the blocks are taken in chunks of 8 * K: within a chunk XCD x takes K
+// CONSECUTIVE blocks (its j-th workgroup of the chunk takes block x * K + j), so neighbouring pixels are written through one L2 at about the same
+// time and leave it as whole lines -- 31.10 MB written, every byte once --, while every XCD still works on an interleaved 1/8 sample of the whole
+// frame.  (The first form gave XCD x the x-th contiguous EIGHTH of the frame: same traffic, but where the cost per pixel varies over the image --
+// retirement, roulette, the grid scenes -- the XCDs then finish far apart: C2 with retirement 15.7 -> 18.3 ms, depth 32 33.3 -> 42.4, C4 +29 %;
+// profiles/r05_variants_xcd_mapping.jsonl.)  The last, partial chunk keeps the identity.  Pure relabelling of independent blocks: no effect on
+// any result.
 template <uint32_t K>
 __device__ __forceinline__ uint32_t xcd_chunked_block(uint32_t wg, uint32_t nwg) {
     constexpr uint32_t kXcds = 8, G = kXcds * K;

@@ -10,9 +10,12 @@ cd "$(dirname "$0")/.." || exit 1
 OUT=gpurun_out/$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-if [ "$PART" = a ]; then
+if [ "$PART" = bench ] || [ "$PART" = headline ]; then   # (the bench step alone / with the headline's rocprofv3 passes)
+  T0=$SECONDS; python bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"; echo "bench.py wall seconds: $((SECONDS - T0))" | tee "$OUT/bench.time"
+  if [ "$PART" = headline ]; then bash profiles/run_profile.sh "$TAG" > "$OUT/prof.log" 2>&1; fi
+elif [ "$PART" = a ]; then
   python -m pytest tests -m gpu -q > "$OUT/tests.log" 2>&1; tail -n 3 "$OUT/tests.log"
-  /usr/bin/time -f "bench.py wall seconds: %e" -o "$OUT/bench.time" python bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"; cat "$OUT/bench.time"
+  T0=$SECONDS; python bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"; echo "bench.py wall seconds: $((SECONDS - T0))" | tee "$OUT/bench.time"
   bash profiles/run_profile.sh "$TAG" > "$OUT/prof.log" 2>&1
   python profiles/configs_bench.py --spp-c4 8 > "$OUT/configs.jsonl" 2> "$OUT/configs.err"; wc -l "$OUT/configs.jsonl"
   for r in "" "--retire"; do

@@ -6,6 +6,7 @@ profiles/hbm_traffic.json (what bench.py reports as roofline.traffic).
 import collections, csv, glob, json, os, shutil, sys
 
 tag = sys.argv[1]
+WARMUP = 3          # run_profile.sh runs bench.py --steps 20 --warmup 3
 src = f"gpurun_out/prof_{tag}"
 here = os.path.dirname(os.path.abspath(__file__))
 newest = lambda pat: max(glob.glob(pat), key=os.path.getmtime)   # gpurun merges runs into gpurun_out/: older passes may still lie there
@@ -20,8 +21,12 @@ for f in sorted(newest(f"{d}/*/*_counter_collection.csv") for d in glob.glob(f"{
         if r["Kernel_Name"] == main["Name"]:
             agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k, v in agg.items():
-        pmc[k] = {"launches": len(v), "avg": sum(v) / len(v)}
-out = {"tag": tag, "command": "python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extra",
+        # (rows are in dispatch order.)  The traffic counters of the process's FIRST launch carry the write-back of the buffers the process has
+        # just zero-filled (torch.zeros of the packed frame slots: 116 MB written / 42 MB fetched "by" that launch in r05, 31.1 / 0.4 by every other
+        # one): the averages that feed hbm_traffic.json are over the TIMED launches, i.e. without the warm-up ones.
+        timed = v[WARMUP:] if k in ("FETCH_SIZE", "WRITE_SIZE") and len(v) > WARMUP else v
+        pmc[k] = {"launches": len(timed), "avg": sum(timed) / len(timed), "first_launch": v[0]}
+out = {"tag": tag, "command": "python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extra --no-traffic-probe",
        "kernel": main["Name"], "calls": int(main["Calls"]), "avg_ns": float(main["AverageNs"]),
        "min_ns": float(main["MinNs"]), "max_ns": float(main["MaxNs"]), "pmc": pmc}
 if "GRBM_GUI_ACTIVE" in pmc:   # summed over the 8 XCDs (MI355X_MICROARCH.md, DVFS give-back)
@@ -52,7 +57,8 @@ if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
                "fetch_bytes_per_launch_corrected_x2": fetch,
                "write_bytes_per_launch": write, "hbm_bytes_per_launch": fetch + write,
                "algorithmic_bytes_per_launch": 1920 * 1080 * 15 + 512,
-               "note": "separate --pmc FETCH_SIZE / --pmc WRITE_SIZE passes; FETCH_SIZE doubled per MI355X_MICROARCH.md"},
+               "note": "separate --pmc FETCH_SIZE / --pmc WRITE_SIZE passes; FETCH_SIZE doubled per MI355X_MICROARCH.md; mean over the 20 timed launches "
+                       "(the process's first launch also writes back the zero-filled buffers: see first_launch in the pmc file)"},
               open(f"{here}/hbm_traffic.json", "w"), indent=1)
 if len(sys.argv) > 2:
     shutil.copy(sys.argv[2], f"{here}/{tag}_bench.json")
