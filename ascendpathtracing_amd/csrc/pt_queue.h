@@ -66,10 +66,19 @@ struct QueueArgs {
 };
 // A colour buffer holds the 4 * n items of a unit as [sub-pixel][sample][3] floats, every sub-pixel's block shifted by 4 more
 // bytes (a block of n * 12 bytes is a multiple of 256 bytes for n = 64: the four chains of a lane group would hit the same banks).
-__host__ __device__ inline uint32_t queue_buf_bytes(uint32_t maxleaf) { return 4u * maxleaf * 12u + 16u; }
+// Sub-pixels per unit.  The 8-sphere form: 4 (a unit = one pairwise leaf of one PIXEL).  The grid form: 2 (a unit = one leaf of HALF a pixel:
+// sub-pixels {0, 1}, then {2, 3}; APT_QUEUE_GRID_SUBS): three buffers of 1544 bytes instead of two of 3088 bring a wave from 6 to 5 LDS
+// granules of 1280 bytes at S = 64, i.e. from 20 to 24 waves per CU together with an 80-register budget -- that kernel hides its latencies with
+// resident waves and little else (profiles/r05_c4_occupancy_sweep.jsonl).  For the 8-sphere form half-pixel units were measured no faster in
+// round 4 (its vector pipe is full; twice as many unit sums cost what the waves return): it keeps whole pixels.
+#ifndef APT_QUEUE_GRID_SUBS
+#define APT_QUEUE_GRID_SUBS 2
+#endif
+__host__ __device__ constexpr uint32_t queue_unit_subs(bool grid) { return grid ? (uint32_t)APT_QUEUE_GRID_SUBS : 4u; }
+__host__ __device__ inline uint32_t queue_buf_bytes(uint32_t maxleaf, uint32_t subs) { return subs * maxleaf * 12u + 4u * subs; }
 // LDS of render_frame_queue8_kernel (all of it dynamic, so that the ray pool sits at LDS address 0 and a pool entry's address
-// needs no base added), in bytes from its start: pool_a | pool_b | scene table | camera | roulette keys | stack | colours
-// (8576 bytes at S = 64 without roulette.  gfx950 hands out LDS in granules of 1280 bytes -- 128 per CU --, so 7 granules = 18 waves per CU
+// needs no base added), in bytes from its start: pool_a | pool_b | scene table | camera | roulette keys | sub-pixel sums | stack | colours
+// (8576 bytes at S = 64 without roulette in the 8-sphere form; the grid form: 6040.  gfx950 hands out LDS in granules of 1280 bytes -- 128 per CU --, so 7 granules = 18 waves per CU
 // whatever is shaved off down to 7680 bytes: a round-4 layout of 8176 bytes -- 16-bit colour addresses in a third pool array, no stored
 // bounce countdown, compact camera -- measured 16.24 against 16.06 ms at C2 with retirement, its two extra address instructions per
 // refill bought nothing.  Only the compact camera is kept.)
@@ -79,19 +88,22 @@ __host__ __device__ constexpr uint32_t queue_lds_off_cam(uint32_t pool) { return
 __host__ __device__ constexpr uint32_t queue_lds_off_key(uint32_t pool) { return queue_lds_off_cam(pool) + (uint32_t)sizeof(CameraLite); }
 // (with roulette: the HIGH words of the keys, 4 bytes per pool entry; the low word takes the place of the bounce countdown in pool_b, which
 // starts at depth - 1 for every ray and is not stored then -- 9072 -> 8816 bytes at S = 64: 7 instead of 8 LDS granules, 18 instead of 16 waves per CU)
-__host__ __device__ inline uint32_t queue_lds_off_stack(uint32_t pool, bool rr) { return queue_lds_off_key(pool) + (rr ? pool * 4u : 0u); }
-__host__ __device__ inline uint32_t queue_lds_off_colq(uint32_t pool, bool rr, bool stack) {
-    return queue_lds_off_stack(pool, rr) + (stack ? (uint32_t)kMaxStack * 3u * 4u * 4u : 0u);
+// (behind the keys, half-pixel units only: 48 bytes = the sums of a pixel's four sub-pixels, [sub][channel], where decode_color's last step
+// reads them -- the sub-pixels of a pixel are summed in different units)
+__host__ __device__ inline uint32_t queue_lds_off_subres(uint32_t pool, bool rr) { return queue_lds_off_key(pool) + (rr ? pool * 4u : 0u); }
+__host__ __device__ inline uint32_t queue_lds_off_stack(uint32_t pool, bool rr, uint32_t subs) { return queue_lds_off_subres(pool, rr) + (subs == 4u ? 0u : 48u); }
+__host__ __device__ inline uint32_t queue_lds_off_colq(uint32_t pool, bool rr, bool stack, uint32_t subs) {
+    return queue_lds_off_stack(pool, rr, subs) + (stack ? (uint32_t)kMaxStack * 3u * 4u * 4u : 0u);
 }
-__host__ __device__ inline uint32_t queue_lds_bytes(uint32_t pool, bool rr, uint32_t nbuf, bool stack, uint32_t buf_bytes) {
-    return queue_lds_off_colq(pool, rr, stack) + nbuf * buf_bytes;
+__host__ __device__ inline uint32_t queue_lds_bytes(uint32_t pool, bool rr, uint32_t nbuf, bool stack, uint32_t buf_bytes, uint32_t subs) {
+    return queue_lds_off_colq(pool, rr, stack, subs) + nbuf * buf_bytes;
 }
 
 #ifndef APT_QUEUE8_WAVES
 #define APT_QUEUE8_WAVES 5 // waves per SIMD the register budget of render_frame_queue8_kernel is set for (96 VGPRs; its 8.6 KB of LDS allow 18 waves per CU at S = 64)
 #endif
 #ifndef APT_QUEUE_GRID_WAVES
-#define APT_QUEUE_GRID_WAVES 5 // the grid form (SC == kSceneGrid) carries a DDA state per lane; 4 / 5 waves measured: 252 / 238 ms at C4 (225 / 213 with retirement)
+#define APT_QUEUE_GRID_WAVES 6 // the grid form (SC == kSceneGrid): 80 registers (14 spilled, outside the walk loop) for a sixth wave per SIMD; with the half-pixel colour units its LDS (5 granules) allows it: 20 -> 24 waves per CU
 #endif
 // RR: APT_FLAG_RR (the host picks the instantiation from ta.rr_start): without it the kernel carries no roulette key and no
 // per-bounce test of the flag.
@@ -104,6 +116,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SC == kScene
                                                                  LeafProg lp, QueueArgs qa) {
     extern __shared__ __align__(16) unsigned char qlds[];
     constexpr uint32_t kPool = queue_pool_entries(SC == kSceneGrid), kPoolBatch = kPool;
+    constexpr uint32_t kSubs = queue_unit_subs(SC == kSceneGrid), kHalves = 4u / kSubs;   // sub-pixels per unit; units per (pixel, leaf)
+    static_assert(kSubs == 4u || kSubs == 2u, "a unit is a pixel or half a pixel");
     // (an LDS pointer made from the integer offset: the dynamic region starts at LDS address 0 -- checked below --, and through `qlds` every table
     // address carried an add of the symbol's link-time value, a v_add_u32 with 0 per bounce)
     typedef __attribute__((address_space(3))) float4 lds_float4;
@@ -133,8 +147,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SC == kScene
     float4 *pool_a = reinterpret_cast<float4 *>(qlds);                 // (ox, oy, dx, dy)
     float4 *pool_b = pool_a + kPool;                                   // (oz, dz, colour address, bounce countdown)
     uint32_t *pool_keyhi = reinterpret_cast<uint32_t *>(qlds + queue_lds_off_key(kPool));     // Russian-roulette key, high word (APT_FLAG_RR only; low word: pool_b[.].w)
-    float *stack = reinterpret_cast<float *>(qlds + queue_lds_off_stack(kPool, rr));     // [kMaxStack][3][4] when nleaves > 1
-    const uint32_t colq_off = queue_lds_off_colq(kPool, rr, nleaves > 1);
+    float *subres = reinterpret_cast<float *>(qlds + queue_lds_off_subres(kPool, rr));   // [4][3]: sums of the pixel's sub-pixels
+    float *stack = reinterpret_cast<float *>(qlds + queue_lds_off_stack(kPool, rr, kSubs));     // [kMaxStack][3][4] when nleaves > 1
+    const uint32_t colq_off = queue_lds_off_colq(kPool, rr, nleaves > 1, kSubs);
     unsigned char *colq = qlds + colq_off;                              // [nbuf][items][3] floats
     constexpr uint32_t qlds_base = 0u;                                  // LDS byte address of the dynamic region (checked above)
     __syncthreads();
@@ -146,16 +161,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SC == kScene
     const uint64_t wb = (uint64_t)xcd_chunked_block<8>(blockIdx.x, gridDim.x) * qa.ppw;   // (XCD-aware: neighbouring pixels through one L2)
 #endif
     const uint32_t npx = (uint32_t)min((uint64_t)qa.ppw, fa.pixel_count - wb);
-    const uint32_t U = npx * nleaves;                                   // units of this wave
+    const uint32_t U = npx * nleaves * kHalves;                         // units of this wave
     const uint64_t q0 = fa.pixel_begin + wb;
 
     // ---- wave-uniform queue state -------------------------------------------------------------------------------
     uint32_t pool_head = 0, pool_level = 0;                             // FIFO ring: entries [head, head + level)
-    uint32_t g_unit = 0, g_off = 0, g_leaf = 0, g_start = 0, g_px = 0, g_buf = 0; // ray-generate cursor
+    uint32_t g_unit = 0, g_off = 0, g_leaf = 0, g_start = 0, g_px = 0, g_buf = 0, g_half = 0; // ray-generate cursor
     uint32_t g_pi = (uint32_t)(q0 / H), g_pj = (uint32_t)(q0 % H);
-    uint32_t a_unit = 0, a_leaf = 0, a_px = 0, a_buf = 0, a_sp = 0;     // accumulation cursor (units are summed in order)
+    uint32_t a_unit = 0, a_leaf = 0, a_px = 0, a_buf = 0, a_sp = 0, a_half = 0;     // accumulation cursor (units are summed in order)
     uint64_t active = 0, alive = 0;                                     // lanes with a running path / that has not hit the light
-    uint32_t issued = 0, a_end = 4u * lp.len(0);                        // items handed to lanes so far / the count at which the oldest unsummed unit ends
+    uint32_t issued = 0, a_end = kSubs * lp.len(0);                     // items handed to lanes so far / the count at which the oldest unsummed unit ends
     uint32_t traced = 0, n_bounce_exec = 0, n_gen_exec = 0, n_exact = 0; // statistics
 
     // ---- per-lane path state ------------------------------------------------------------------------------------
@@ -172,16 +187,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SC == kScene
     // ---- ray-generate: the next <= 64 items of the current unit into the pool ---------------------------------------
     auto gen_batch = [&]() __attribute__((always_inline)) {
         ++n_gen_exec;
-        const uint32_t nl = lp.len(g_leaf), items = 4u * nl;
+        const uint32_t nl = lp.len(g_leaf), items = kSubs * nl;
         const uint32_t nb = min(kPoolBatch, items - g_off);
         const bool on = lane < nb;
-        const uint32_t i = g_off + (on ? lane : 0u);                    // item within the unit: sub * nl + k
-        const uint32_t sub = (i >= nl ? 1u : 0u) + (i >= 2u * nl ? 1u : 0u) + (i >= 3u * nl ? 1u : 0u);
+        const uint32_t i = g_off + (on ? lane : 0u);                    // item within the unit: (sub - first sub of the unit) * nl + k
+        const uint32_t sl = kSubs == 4u ? (i >= nl ? 1u : 0u) + (i >= 2u * nl ? 1u : 0u) + (i >= 3u * nl ? 1u : 0u) : (i >= nl ? 1u : 0u);
+        const uint32_t sub = sl + kSubs * g_half;                       // (whole-pixel units: g_half stays 0)
         // path = ((q0 + g_px) * 4 + sub) * S + g_start + k (gen_data.py:32-36) with k = i - sub * nl, i.e. a wave-uniform base plus a
         // 32-bit per-lane offset: the 64-bit index arithmetic and the generator state of the base run on the scalar unit, a lane adds
         // offset * stride (one 32 x 64 bit product) -- round 3 formed the 64-bit path index and its 64 x 64 bit product per lane.
         const uint64_t base = (q0 + g_px) * 4u * (uint64_t)S + g_start;
-        const uint32_t off = i + sub * (S - nl);                        // < 4 * S
+        const uint32_t off = i - sl * nl + sub * S;                     // = sub * S + k  (< 4 * S)
         const uint64_t path = base + off;
         double u1, u2;
         // (splitmix64(seed) is recomputed here, on the scalar unit, rather than kept in two scalar registers across the hot loop)
@@ -194,7 +210,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SC == kScene
         const uint32_t e = pool_level + lane;
         if (on) {
             pool_a[e] = make_float4(rox, roy, rdx, rdy);
-            const uint32_t ca = qlds_base + colq_off + g_buf * qa.buf_bytes + i * 12u + sub * 4u;
+            const uint32_t ca = qlds_base + colq_off + g_buf * qa.buf_bytes + i * 12u + sl * 4u;
             if (rr) {
                 // what the roulette of this path hashes at shading bounce d is splitmix64(key + phi * (d + 1)), and splitmix64 starts by adding
                 // phi: the entry carries key + phi * rr_start, the state one step before the path's first roulette (d = rr_start - 1), and
@@ -208,12 +224,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SC == kScene
         }
         pool_level += nb;
         g_off += nb;
-        if (g_off == items) {                                           // next unit: next leaf of the pixel, or the next pixel
-            g_off = 0; ++g_unit; g_start += nl;
+        if (g_off == items) {                                           // next unit: (the other half of this leaf,) the next leaf of the pixel, or the next pixel
+            g_off = 0; ++g_unit;
             if (++g_buf == nbuf) g_buf = 0;
-            if (++g_leaf == nleaves) {
-                g_leaf = 0; g_start = 0; ++g_px;
-                if (++g_pj == H) { g_pj = 0; ++g_pi; }
+            if (kHalves == 1u || ++g_half == kHalves) {
+                g_half = 0; g_start += nl;
+                if (++g_leaf == nleaves) {
+                    g_leaf = 0; g_start = 0; ++g_px;
+                    if (++g_pj == H) { g_pj = 0; ++g_pi; }
+                }
             }
         }
         __syncthreads(); // one wave per workgroup: orders the pool writes before the reads of other lanes
@@ -223,9 +242,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SC == kScene
     auto accumulate_unit = [&]() __attribute__((always_inline)) {
         __syncthreads();
         const uint32_t nl = lp.len(a_leaf), nfull = nl & ~7u, nt = nl - nfull;
-        const uint32_t sub = (lane >> 3) & 3u, j = lane & 7u;          // lanes 32..63 repeat the work of lanes 0..31
+        const uint32_t sl = (lane >> 3) & (kSubs - 1u), j = lane & 7u; // sub-pixel within the unit; lanes beyond 8 * kSubs repeat the work of the first
+        const uint32_t sub = sl + kSubs * a_half;                       // sub-pixel of the pixel (whole-pixel units: a_half stays 0)
         const float *col = reinterpret_cast<const float *>(colq + a_buf * qa.buf_bytes);
-        const uint32_t base = (sub * nl + j) * 3u + sub;                // the sub-pixel's block is shifted by sub * 4 bytes
+        const uint32_t base = (sl * nl + j) * 3u + sl;                  // the sub-pixel's block is shifted by 4 bytes per sub-pixel
         float acc[3];
         acc[0] = col[base] * gain.r; acc[1] = col[base + 1] * gain.g; acc[2] = col[base + 2] * gain.b; // render.cpp:194-196
         for (uint32_t i8 = 8; i8 < nfull; i8 += 8) {                    // numpy's chain r[j] += a[j + 8m]
@@ -241,7 +261,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SC == kScene
             acc[ch] = v;
         }
         if (nt) {                                                       // res += a[i] for the n % 8 trailing samples, in order
-            const uint32_t o = (sub * nl + nfull + (j < nt ? j : 0u)) * 3u + sub;
+            const uint32_t o = (sl * nl + nfull + (j < nt ? j : 0u)) * 3u + sl;
             const float cr = col[o] * gain.r, cg = col[o + 1] * gain.g, cb = col[o + 2] * gain.b;
             for (uint32_t t = 0; t < nt; ++t) {
                 const int src = (int)((lane & ~7u) + t);
@@ -251,47 +271,72 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SC == kScene
             }
         }
         float res[3] = {acc[0], acc[1], acc[2]};
+        const bool last_half = kHalves == 1u || a_half + 1u == kHalves; // (the units of one leaf run the same stack program from the same level, each on its own sub-pixels' slots)
         if (nleaves > 1) {                                              // pairwise(left) + pairwise(right), innermost first
+            uint32_t sp = a_sp;
 #pragma unroll
-            for (int ch = 0; ch < 3; ++ch) stack[(a_sp * 3 + ch) * 4 + sub] = acc[ch]; // the lanes of a group hold equal values
-            ++a_sp;
+            for (int ch = 0; ch < 3; ++ch) stack[(sp * 3 + ch) * 4 + sub] = acc[ch]; // the lanes of a group hold equal values
+            ++sp;
             for (uint32_t m = 0; m < lp.ncomb(a_leaf); ++m) {
-                --a_sp;
+                --sp;
 #pragma unroll
                 for (int ch = 0; ch < 3; ++ch) {
-                    const float x = stack[((a_sp - 1) * 3 + ch) * 4 + sub], y = stack[(a_sp * 3 + ch) * 4 + sub];
-                    stack[((a_sp - 1) * 3 + ch) * 4 + sub] = x + y;
+                    const float x = stack[((sp - 1) * 3 + ch) * 4 + sub], y = stack[(sp * 3 + ch) * 4 + sub];
+                    stack[((sp - 1) * 3 + ch) * 4 + sub] = x + y;
                 }
             }
 #pragma unroll
             for (int ch = 0; ch < 3; ++ch) res[ch] = stack[ch * 4 + sub];
+            if (last_half) a_sp = sp;
         }
         if (a_leaf + 1 == nleaves) {                                    // decode_color: data_visualization.py:36-57
-            // The lanes of a group hold equal sums for all three channels: lane j of a group decodes channel j (j < 3; the others repeat
-            // channel 0), so the divide, the float64 mean of the four sub-pixels and the clamp run ONCE per pixel instead of once per channel
-            // (round 4: ~60 of the ~205 vector instructions a wave spends per pixel outside the bounces; C2 with retirement 16.0 -> 15.75 ms.
-            // Going further -- the lower half of the wave summing (r, g) as packed pairs, the upper half b -- measured no faster.)
             const float fs = (float)S;
             const uint64_t pl = wb + a_px;
-            const int src0 = (int)((lane & ~31u) + j);                  // the lane with this channel in sub-pixel group 0 of this half of the wave
-            const uint32_t ch = j < 3u ? j : 0u;
-            const float r = j == 1u ? res[1] : (j == 2u ? res[2] : res[0]);
-            const float mean = r / fs;                                  // np.mean: float32 sum / count
-            double a64 = 0.0;                                           // :38 sum_color = zeros (float64)
+            if (kSubs == 4u) {
+                // The lanes of a group hold equal sums for all three channels: lane j of a group decodes channel j (j < 3; the others repeat
+                // channel 0), so the divide, the float64 mean of the four sub-pixels and the clamp run ONCE per pixel instead of once per channel
+                // (round 4: ~60 of the ~205 vector instructions a wave spends per pixel outside the bounces; C2 with retirement 16.0 -> 15.75 ms.
+                // Going further -- the lower half of the wave summing (r, g) as packed pairs, the upper half b -- measured no faster.)
+                const int src0 = (int)((lane & ~31u) + j);              // the lane with this channel in sub-pixel group 0 of this half of the wave
+                const uint32_t ch = j < 3u ? j : 0u;
+                const float r = j == 1u ? res[1] : (j == 2u ? res[2] : res[0]);
+                const float mean = r / fs;                              // np.mean: float32 sum / count
+                double a64 = 0.0;                                       // :38 sum_color = zeros (float64)
 #pragma unroll
-            for (int sq = 0; sq < 4; ++sq) a64 = a64 + (double)__shfl(mean, src0 + sq * 8, 64); // :41-45
-            const double v = a64 / 4;                                   // :46
-            const double cl = v < 0 ? 0 : (v > 1 ? 1 : v);              // :54
-            if (lane < 3u) {
-                fa.fb[(uint64_t)ch * fa.pixel_count + pl] = (float)cl;
-                if (fa.fb_u8) fa.fb_u8[pl * 3 + ch] = (uint8_t)(cl * 255); // :55-57 truncation
+                for (int sq = 0; sq < 4; ++sq) a64 = a64 + (double)__shfl(mean, src0 + sq * 8, 64); // :41-45
+                const double v = a64 / 4;                               // :46
+                const double cl = v < 0 ? 0 : (v > 1 ? 1 : v);          // :54
+                if (lane < 3u) {
+                    fa.fb[(uint64_t)ch * fa.pixel_count + pl] = (float)cl;
+                    if (fa.fb_u8) fa.fb_u8[pl * 3 + ch] = (uint8_t)(cl * 255); // :55-57 truncation
+                }
+                a_sp = 0;
+            } else {
+                // half-pixel units: this unit's sub-pixel sums go to LDS; after the pixel's last unit the same decode reads all four from there
+                if (lane < 8u * kSubs && j < 3u) subres[sub * 3u + j] = j == 1u ? res[1] : (j == 2u ? res[2] : res[0]);
+                if (last_half) {
+                    __syncthreads();
+                    const uint32_t ch = lane < 3u ? lane : 0u;
+                    double a64 = 0.0;                                   // :38 sum_color = zeros (float64)
+#pragma unroll
+                    for (int sq = 0; sq < 4; ++sq) a64 = a64 + (double)(subres[sq * 3 + ch] / fs);   // np.mean: float32 sum / count; :41-45
+                    const double v = a64 / 4;                           // :46
+                    const double cl = v < 0 ? 0 : (v > 1 ? 1 : v);      // :54
+                    if (lane < 3u) {
+                        fa.fb[(uint64_t)ch * fa.pixel_count + pl] = (float)cl;
+                        if (fa.fb_u8) fa.fb_u8[pl * 3 + ch] = (uint8_t)(cl * 255); // :55-57 truncation
+                    }
+                    a_sp = 0;
+                }
             }
-            a_sp = 0;
         }
         ++a_unit;
         if (++a_buf == nbuf) a_buf = 0;
-        if (++a_leaf == nleaves) { a_leaf = 0; ++a_px; }
-        a_end += 4u * lp.len(a_leaf);                                   // (past the wave's last unit the value is never used)
+        if (kHalves == 1u || ++a_half == kHalves) {
+            a_half = 0;
+            if (++a_leaf == nleaves) { a_leaf = 0; ++a_px; }
+        }
+        a_end += kSubs * lp.len(a_leaf);                                // (past the wave's last unit the value is never used)
         __syncthreads();
     };
     // Are all items of the oldest unsummed unit parked?  They are when every one of them has been handed to a lane (the pool is a

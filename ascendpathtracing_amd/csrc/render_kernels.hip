@@ -166,16 +166,17 @@ int do_render_paths(const Launch &ls, const apt_render_params *p, void *stream, 
 // The sample-queue kernels' launch shape (pt_queue.h): colour buffers, pixels per wave, dynamic LDS.  -> false: too many waves.
 bool queue_launch_shape(const apt::Debug &dbg, const LeafProg &lp, bool rr, bool grid, uint64_t pixel_count, bool retire, QueueArgs &qa,
                         uint64_t &waves, size_t &qlds) {
-    const uint32_t unit_items = 4u * lp.maxleaf;
-    qa.nbuf = dbg.queue_nbuf ? dbg.queue_nbuf : std::max(2u, std::min(16u, (512u + unit_items - 1u) / unit_items));
-    qa.buf_bytes = queue_buf_bytes(lp.maxleaf);
+    // a unit = one pairwise leaf of a pixel (8-sphere form) or of half a pixel (grid form); buffers for ~512 resp. ~384 items in flight
+    const uint32_t subs = queue_unit_subs(grid), unit_items = subs * lp.maxleaf, window = subs == 4u ? 512u : 384u;
+    qa.nbuf = dbg.queue_nbuf ? dbg.queue_nbuf : std::max(2u, std::min(16u, (window + unit_items - 1u) / unit_items));
+    qa.buf_bytes = queue_buf_bytes(lp.maxleaf, subs);
     qa.retire = retire ? 1u : 0u;
     // pixels per wave: 16 at C2 (lane efficiency 0.98; 8 / 16 / 24 measured within 0.5 % of each other, 2 costs 6 %), fewer only
     // for frames too small to fill the chip's ~3800 wave slots a few times over
     const uint64_t ppw = dbg.queue_ppw ? dbg.queue_ppw : std::max<uint64_t>(4, std::min<uint64_t>(16, pixel_count / 8192u));
     qa.ppw = (uint32_t)ppw;
     waves = (pixel_count + ppw - 1) / ppw;
-    qlds = queue_lds_bytes(queue_pool_entries(grid), rr, qa.nbuf, lp.nleaves > 1, qa.buf_bytes) + dbg.queue_lds_pad;   // the pad: experiments only, lowers the occupancy
+    qlds = queue_lds_bytes(queue_pool_entries(grid), rr, qa.nbuf, lp.nleaves > 1, qa.buf_bytes, subs) + dbg.queue_lds_pad;   // the pad: experiments only, lowers the occupancy
     return waves <= 0x7fffffffull;
 }
 
