@@ -415,12 +415,12 @@ def main():
         return dry_run(args)
     if args.traffic_probe:
         return traffic_probe()
-    live = None
-    if args.gpus == 1 and "WORLD_SIZE" not in os.environ and args.workload in ("auto", "c2") and not args.no_traffic_probe:
-        live = measure_traffic()              # child processes; this process has not touched the GPU yet
-
     import __graft_entry__
     __graft_entry__.build()                   # incremental, serialised by a file lock; does not touch the GPU
+
+    live = None
+    if args.gpus == 1 and "WORLD_SIZE" not in os.environ and args.workload in ("auto", "c2") and not args.no_traffic_probe:
+        live = measure_traffic()              # child processes (they find the library built); this process has not touched the GPU yet
 
     import torch
     import torch.distributed as dist
