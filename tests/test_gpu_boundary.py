@@ -325,9 +325,8 @@ def _nccl_pipeline_worker(rank, world, port, out_path, frames):
     """One process per GPU (bench.py's shape): `frames` frames of DIFFERENT content through the double-buffered asynchronous gather."""
     import os
     import sys
-    from conftest import ROOT
-    sys.path.insert(0, ROOT)
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")   # (a spawned child: its own environment)
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))     # the repository root (a spawned child: no conftest here)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")   # (its own environment)
     import torch.distributed as dist
     torch.cuda.set_device(rank)
     dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
