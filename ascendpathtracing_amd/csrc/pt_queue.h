@@ -56,7 +56,7 @@ struct FrameArgs {
 #endif
 // Ray pool entries per wave = rays generated at a time (one batch fills the empty pool).  The 8-sphere form: 64, one per lane (ray-generate is
 // a quarter of that kernel).  The grid form: 32 -- ray-generate is 2 % of a frame there, a half-empty generate pass costs nothing
-// measurable, and the 1024 bytes of LDS bring the wave to 6 granules of 1280 bytes instead of 7: 20 instead of 18 waves per CU.
+// measurable, and the 1024 bytes of LDS it saves are a granule of 1280 bytes (round 4: 7 -> 6 granules; with round 5's half-pixel colour units 5).
 __host__ __device__ constexpr uint32_t queue_pool_entries(bool grid) { return grid ? 32u : (uint32_t)APT_Q8_POOL; }
 struct QueueArgs {
     uint32_t ppw;        // pixels per wave
@@ -128,9 +128,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SC == kScene
     // descriptor's group_segment_fixed_size); a build that breaks this renders nothing rather than reading the wrong pool entries.
     if ((uint32_t)(uintptr_t)qlds != 0u) { report_status(ta, APT_DEV_LDS_BASE); return; }
     if (SC == kSceneGrid && !grid_queue_usable(ta)) {                  // wave-uniform: render_frame_kernel renders this frame (its grid_walk == 2) --
-#ifndef APT_NO_GRID_ASSERT   // A/B builds only
         if (ta.grid_walk == 3u) report_status(ta, APT_DEV_GRID_MISMATCH);   // or, under APT_FLAG_GRID_SLOTS, nobody does: the caller's promise did not hold
-#endif
         return;
     }
     if (lane == 0) cam = camera_lite(fa.cam);

@@ -111,13 +111,8 @@ __device__ __forceinline__ void report_status(const TraceArgs &ta, uint32_t bit)
 // all three products are -0: the sum is then +0 with it and -0 without.  The one consumer is k2 = dot * 2 (:697), and fma(dot, 2, +0)
 // is that product exactly (a doubling never rounds; overflow and NaN go the same way) with -0 turned into +0 by the addend: the start
 // value's whole effect for the price of the multiply itself.  (The norm's products are squares, never -0: nothing to preserve there.)
-#ifdef APT_NO_TWICE_CANON   // A/B builds only (timing: not bit-exact for an all -0 dot product)
-__device__ __forceinline__ float twice_canonical(float dot) { return dot * 2.0f; }
-__device__ __forceinline__ f2 twice_canonical(f2 dot) { return dot * 2.0f; }
-#else
 __device__ __forceinline__ float twice_canonical(float dot) { return __builtin_fmaf(dot, 2.0f, 0.0f); }
 __device__ __forceinline__ f2 twice_canonical(f2 dot) { return __builtin_elementwise_fma(dot, f2{2.0f, 2.0f}, f2{0.0f, 0.0f}); }
-#endif
 
 struct HitPre2 { f2 b, disc; };
 __device__ __forceinline__ HitPre2 intersect_pre2(const f2 cx, const f2 cy, const f2 cz, const f2 r2, float ox,

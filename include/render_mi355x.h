@@ -45,7 +45,7 @@ extern "C" {
 #pragma GCC visibility push(default)
 #endif
 
-#define APT_ABI_VERSION 3
+#define APT_ABI_VERSION 3   /* additive since 3 (round 5): apt_grid_flags, apt_context_get_debug / apt_get_debug, APT_FLAG_GRID_SLOTS, APT_DEV_GRID_MISMATCH */
 
 /* status codes returned by the *_ex / frame entry points (render_do itself is void,
  * like the reference, and reports through apt_last_status() / apt_last_error()). */
