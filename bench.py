@@ -608,4 +608,14 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    except SystemExit:
+        raise
+    except BaseException as e:               # noqa: BLE001 -- a multi-GPU run that dies must still say WHY on the one line the driver reads
+        import traceback
+        traceback.print_exc()
+        if int(os.environ.get("RANK", "0")) == 0:
+            print(json.dumps({"metric": "Mray/s (ray segments per second)", "value": None, "unit": "Mray/s",
+                              "n_gpus": int(os.environ.get("WORLD_SIZE", "1")), "error": f"{type(e).__name__}: {e}"[:500]}), flush=True)
+        sys.exit(1)
