@@ -289,8 +289,8 @@ int apt_gen_scene_host(uint32_t num_spheres, uint64_t seed, float *spheres, size
     return APT_OK;
 }
 
-// Uniform grid for scenes with many spheres (apt_render_params.accel).  Spheres whose radius exceeds
-// twice the median radius... are "large" (the walls and the light of the generated scenes, r >= 600):
+// Uniform grid for scenes with many spheres (apt_render_params.accel).  Spheres whose radius exceeds 8x the median
+// radius, or that are not finite (pt_core.h grid_is_large), are "large" (the walls and the light of the generated scenes, r >= 600):
 // they go to an always-tested list; the others are binned by their bounding boxes, inflated by `margin`
 // so that any ray the fp32 intersection formula can possibly accept passes through the interior of a
 // cell that lists the sphere (the formula's absolute error on disc is ~1e-3 at these coordinates; the

@@ -200,13 +200,9 @@ __device__ __forceinline__ bool div3_operands_ok(float len2, float nx, float ny,
 }
 #endif
 
-// The two roots b -/+ q of one ray/sphere pair; FAST uses sqrt_rn_rsq1 on the device.
-// sqrt_rn_rsq1 differs from sqrtf() for exactly one input, +inf (NaN instead of +inf); an
-// infinite discriminant makes t = +inf with sqrtf() and kMissT with the NaN, and neither can win
-// the strict '<' arg-min against tmin <= kMissT, so the selected sphere and tmin are unchanged.
-template <bool FAST>
+// The two roots b -/+ q of one ray/sphere pair in the reference's own form (rt_helper.h:263-331), sqrtf() for the square root.
 APT_HD void intersect_roots(float cx, float cy, float cz, float r2, float ox, float oy, float oz, float dx, float dy,
-                            float dz, float &t0, float &t1, float &amin) {
+                            float dz, float &t0, float &t1) {
     float ocx = cx - ox, ocy = cy - oy, ocz = cz - oz;
     float b = ocx * dx;
     b = b + ocy * dy;
@@ -217,13 +213,7 @@ APT_HD void intersect_roots(float cx, float cy, float cz, float r2, float ox, fl
     c = c - r2;
     float disc = b * b;
     disc = disc - c;
-    float q;
-#if defined(__HIP_DEVICE_COMPILE__)
-    if (FAST) q = sqrt_rn_rsq1(disc, amin);
-    else
-#endif
-        q = sqrtf(disc);
-    (void)amin;
+    const float q = sqrtf(disc);
     t0 = b - q;
     t1 = b + q;
 }
@@ -241,12 +231,7 @@ APT_HD float select_root(float t0, float t1, float eps) {
 // either sign wrap to keys above every acceptable one.  Since t1 >= t0 whenever both are numbers,
 // "t0 if t0 > eps else t1 if t1 > eps else miss" is min(key(t0), key(t1)), and a root beats the
 // running minimum (initially kMissT) exactly when its key is below the running key (initially
-// key(kMissT)), so tmin = value(running key) needs no select at the end.
-struct RootKey {
-    uint32_t bias;  // u(eps) + 1
-    uint32_t best;  // running minimum key, starts at key(kMissT)
-    int idx;        // sphere of the running minimum (lowest index on ties: strict '<')
-};
+// key(kMissT)), so tmin = value(running key) needs no select at the end.  (pt_trace.h KeyConsts / intersect_ns8_v2, pt_queue.h test_post.)
 APT_HD uint32_t f32_bits(float x) {
 #if defined(__HIP_DEVICE_COMPILE__)
     return __float_as_uint(x);
@@ -261,24 +246,6 @@ APT_HD float bits_f32(uint32_t u) {
     union { float f; uint32_t u; } v; v.u = u; return v.f;
 #endif
 }
-APT_HD void rootkey_init(RootKey &k, float eps, int miss_idx) {
-    k.bias = f32_bits(eps) + 1u;
-    k.best = f32_bits(kMissT) - k.bias;
-    k.idx = miss_idx;
-}
-APT_HD void rootkey_update(RootKey &k, float t0, float t1, int sphere) {
-    const uint32_t m0 = f32_bits(t0) - k.bias, m1 = f32_bits(t1) - k.bias;
-    uint32_t nb;
-#if defined(__HIP_DEVICE_COMPILE__)
-    asm("v_min3_u32 %0, %1, %2, %3" : "=v"(nb) : "v"(k.best), "v"(m0), "v"(m1)); // one 4-cycle op instead of two
-#else
-    const uint32_t m = m0 < m1 ? m0 : m1;
-    nb = m < k.best ? m : k.best;
-#endif
-    k.idx = (nb != k.best) ? sphere : k.idx;
-    k.best = nb;
-}
-APT_HD float rootkey_tmin(const RootKey &k) { return bits_f32(k.best + k.bias); }
 APT_HD bool eps_allows_rootkey(float eps) { return eps > 0.0f && eps < kMissT; }
 
 #if defined(__clang__) // everything from here to the matching #endif is used by the kernels only (hipcc = clang)

@@ -128,7 +128,7 @@ __global__ __launch_bounds__(kBlock) void render_paths_queue_kernel(const float 
     auto step_exact = [&](PathState &in, PathState &out) {
         const bool active = depth_left != 0;
         in.rxy = thr_xy; in.rz = thr_z; in.alive = select_const(alive, 1);
-        (void)bounce_ns8<MODE, false>(sc, tab8, in, out, ta);
+        bounce_ns8_exact<MODE>(sc, tab8, in, out, ta);
         thr_xy = out.rxy; thr_z = out.rz;
         alive = __builtin_amdgcn_ballot_w64(out.alive != 0);
         post(active);

@@ -153,11 +153,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SC == kScene
     __syncthreads();
 
     // this wave's pixels
-#ifdef APT_QUEUE_NO_XCD   // A/B builds only
-    const uint64_t wb = (uint64_t)blockIdx.x * qa.ppw;
-#else
     const uint64_t wb = (uint64_t)xcd_chunked_block<8>(blockIdx.x, gridDim.x) * qa.ppw;   // (XCD-aware: neighbouring pixels through one L2)
-#endif
     const uint32_t npx = (uint32_t)min((uint64_t)qa.ppw, fa.pixel_count - wb);
     const uint32_t U = npx * nleaves * kHalves;                         // units of this wave
     const uint64_t q0 = fa.pixel_begin + wb;
@@ -550,7 +546,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SC == kScene
                     ++n_exact;
                     PathState c = s, o;
                     c.rxy = thr_xy; c.rz = thr_z; c.alive = select_const(alive, 1);
-                    (void)bounce_ns8<MODE, false>(sc, tab8, c, o, ta);
+                    bounce_ns8_exact<MODE>(sc, tab8, c, o, ta);
                     s.oxy = o.oxy; s.oz = o.oz; s.dxy = o.dxy; s.dz = o.dz;
                     thr_xy = o.rxy; thr_z = o.rz;
                     alive = __builtin_amdgcn_ballot_w64(o.alive != 0);
@@ -845,15 +841,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SC == kScene
                 // the x / y components); outside the fast sequences' range the step is redone with sqrtf() and '/'
                 PathState n;
                 const float amin = reflect_packed<MODE>(s, tmin, gc.x, gc.y, gc.z, n);
-#ifdef APT_ABL_SHADE2   // measurement only (same image): the reflection computed twice
-                {
-                    PathState n2;
-                    float t2 = tmin;
-                    asm volatile("" : "+v"(t2));
-                    const float a2 = reflect_packed<MODE>(s, t2, gc.x, gc.y, gc.z, n2);
-                    asm volatile("" :: "v"(a2), "v"(n2.oxy), "v"(n2.oz), "v"(n2.dxy), "v"(n2.dz));
-                }
-#endif
                 if (__builtin_expect(__builtin_amdgcn_ballot_w64(!(amin >= kFastMin)) != 0, 0)) {
                     asm volatile("" ::: "memory");
                     PathState c = s;
@@ -913,9 +900,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SC == kScene
                     bestk = f32_bits(tmin) - kbias;             // tmin is kMissT or an accepted root: its key is exact
                     bestp = kIdFlag | idx;
                 } else {
-#ifdef APT_ABL_LARGE2   // measurement only (same image): the always-tested list evaluated twice -- the time difference is what one pass costs
-                    for (int rep = 0; rep < 2; ++rep)
-#endif
                     {
                         // the always-tested list: its first kBigLds pair slots from LDS (uniform addresses: broadcasts, all in flight together;
                         // pads are NaN spheres), the rest -- scenes with more than 2 * kBigLds large spheres -- by scalar loads
@@ -1066,9 +1050,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SC == kScene
             atomicAdd(ta.traced + 2, 64ull * n_gen_exec);
         }
         if (n_exact) atomicAdd(ta.traced + 3, (unsigned long long)n_exact);
-#ifdef APT_GRID_DEBUG_STATS   // measurement build only: lane-slots of the per-segment block in the "exact re-runs" slot
-        if (SC == kSceneGrid) atomicAdd(ta.traced + 3, 64ull * n_bounce_exec);
-#endif
     }
 }
 

@@ -168,70 +168,34 @@ __device__ __forceinline__ void intersect_pre_planes(const Scene8 &sc, float ox,
 }
 
 // ---- trace: reference scene (Ns == 8) ----------------------------------------------------
-// One bounce: 8 intersections (sphere operands in SGPRs), arg-min, gather, shade.
-// FAST: exact fast sqrt sequences (pt_core.h) and, when eps permits, the integer-key arg-min.
-template <int MODE, bool FAST>
-__device__ __forceinline__ bool bounce_ns8(const Scene8 &sc, const Tab8 tab, const PathState &s, PathState &n,
-                                           const TraceArgs &ta) {
-    float amin = 1.0f; // min |sqrt argument| of this bounce (FAST only)
-    float tmin;
-    int idx;
+// One bounce in the reference's own float form: 8 intersections (sphere operands in SGPRs) with sqrtf(), select_root's two
+// selects and the strict-'<' arg-min, gather, shade with sqrtf() and '/'.  The COLD form: what a wave falls back to when a lane
+// leaves the validity range of the fast sequences below, or when eps does not permit the integer root keys.
+template <int MODE>
+__device__ __forceinline__ void bounce_ns8_exact(const Scene8 &sc, const Tab8 tab, const PathState &s, PathState &n,
+                                                 const TraceArgs &ta) {
     const int miss = (MODE == kModeOracle) ? -1 : 0; // all-miss: gen_data.py:311 / rt_helper.h:183-201
-    if (FAST) {
-        RootKey key;
-        rootkey_init(key, ta.eps, miss);
-#if defined(APT_NS8_SCALAR) // A/B switch: one sphere per scalar instruction stream
+    float tmin = kMissT;
+    int idx = miss;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            float t0, t1;
-            intersect_roots<true>(sc.cx[k], sc.cy[k], sc.cz[k], sc.r2[k], s.oxy.x, s.oxy.y, s.oz, s.dxy.x, s.dxy.y, s.dz, t0, t1,
-                                  amin);
-            rootkey_update(key, t0, t1, k);
-        }
-#else
-#pragma unroll
-        for (int k = 0; k < 8; k += 2) { // rt_helper.h:457-467, two spheres per packed instruction
-            const HitPre2 h = intersect_pre2(f2{sc.cx[k], sc.cx[k + 1]}, f2{sc.cy[k], sc.cy[k + 1]},
-                                             f2{sc.cz[k], sc.cz[k + 1]}, f2{sc.r2[k], sc.r2[k + 1]}, s.oxy.x, s.oxy.y, s.oz,
-                                             s.dxy.x, s.dxy.y, s.dz);
-            // sqrt_rn_rsq1 on both lanes of the pair (pt_core.h): y = x*r, hh = r/2, q = fma(fma(-y,y,x), hh, y)
-            amin = fminf(amin, fminf(fabsf(h.disc.x), fabsf(h.disc.y)));
-            const f2 r0 = {__builtin_amdgcn_rsqf(h.disc.x), __builtin_amdgcn_rsqf(h.disc.y)};
-            const f2 y = h.disc * r0, hh = r0 * 0.5f;
-            const f2 res = __builtin_elementwise_fma(-y, y, h.disc);
-            const f2 q = __builtin_elementwise_fma(res, hh, y);
-            const f2 t0 = h.b - q, t1 = h.b + q;
-            rootkey_update(key, t0.x, t1.x, k);
-            rootkey_update(key, t0.y, t1.y, k + 1);
-        }
-#endif
-        tmin = rootkey_tmin(key);
-        idx = key.idx;
-    } else {
-        tmin = kMissT;
-        idx = miss;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            float t0, t1;
-            intersect_roots<false>(sc.cx[k], sc.cy[k], sc.cz[k], sc.r2[k], s.oxy.x, s.oxy.y, s.oz, s.dxy.x, s.dxy.y, s.dz, t0, t1,
-                                   amin);
-            const float t = select_root(t0, t1, ta.eps);
-            if (t < tmin) { tmin = t; idx = k; } // strict '<', ascending k: lowest index wins ties
-        }
+    for (int k = 0; k < 8; ++k) {
+        float t0, t1;
+        intersect_roots(sc.cx[k], sc.cy[k], sc.cz[k], sc.r2[k], s.oxy.x, s.oxy.y, s.oz, s.dxy.x, s.dxy.y, s.dz, t0, t1);
+        const float t = select_root(t0, t1, ta.eps);
+        if (t < tmin) { tmin = t; idx = k; } // strict '<', ascending k: lowest index wins ties
     }
     const int g = (idx < 0) ? 7 : idx; // Python index -1 wraps to the last sphere
     const float4 c = tab.geo[g], col = tab.alb[g];
     n = s;
-    shade_and_reflect<MODE, FAST>(n, tmin, c.x, c.y, c.z, col.x, col.y, col.z, idx == ta.light, &amin);
-    // the fast sequences are only valid for |sqrt argument| >= 2^-96 and 0 < eps < 1e20
-    return FAST && (amin < 0x1p-96f || !eps_allows_rootkey(ta.eps));
+    shade_and_reflect<MODE>(n, tmin, c.x, c.y, c.z, col.x, col.y, col.z, idx == ta.light);
 }
 
-// ---- the same bounce with fewer half-rate instructions (APT_BOUNCE_V2, default) ---------------------------
+// ---- the hot form of that bounce ---------------------------------------------------------------------------
 // On gfx950 a wave64 VALU instruction issues in ~2.5 cycles when it is a plain fp32/int32 operation on VGPRs
 // and in ~4.3 cycles when it is a compare, select, min/max, or has an SGPR operand (profiles/microbench/
 // valu_rates_mi355x.txt); the bounce block is VALU-issue bound, so its time is the sum of those costs.  Same
-// arithmetic as bounce_ns8<MODE, true>, instruction for instruction in the fp32 data path; what changes:
+// arithmetic as bounce_ns8_exact in the fp32 data path, with the exact fast sqrt sequence (pt_core.h sqrt_rn_rsq1) and the
+// integer root keys (pt_core.h, "the same selection ... in the integer domain"); how it is written:
 //   * the root-key bias and start value live in VGPRs (KeyConsts): the 16 integer subtractions per bounce no
 //     longer carry an SGPR operand (half rate -> full rate);
 //   * the arg-min index is not tracked per lane with compare + select per sphere: the 8 "sphere k improved the
@@ -253,9 +217,6 @@ __device__ __forceinline__ KeyConsts make_key_consts(float eps) {
     asm volatile("" : "+s"(kc.nbias2));
     return kc;
 }
-#ifndef APT_KEY64
-#define APT_KEY64 1
-#endif
 // (-t0, t1) = (q - b, b + q) of ONE sphere as the two halves of a register pair, from the packed (sphere k, sphere k+1)
 // operands: v_pk_add_f32 with both result halves reading half `HALF` of the sources and the low half negating b
 // (exact: round-to-nearest is symmetric, q - b is -(b - q) bit for bit).
@@ -330,23 +291,6 @@ __device__ __forceinline__ Hit8 intersect_ns8_v2(const Scene8 &sc, float ox, flo
                                                  const TraceArgs &ta, const KeyConsts &kc, float &amin) {
     uint32_t best = kc.init;
     uint64_t b0 = 0, b1 = 0, b2 = 0, any = 0;
-#ifdef APT_T_EXTRA // measurement only (profiles/microbench/insitu_costs.sh): N extra independent instructions of one class per bounce
-    {
-        float x0 = ox, x1 = oy, x2 = oz, x3 = dx;
-        f2 y0 = {ox, oy}, y1 = {oz, dx};
-#define APT_R4(a) a a a a
-#if APT_T_EXTRA == 1   // 16 plain
-#define APT_T_OPS "v_add_f32 %0, %0, %6\n v_add_f32 %1, %1, %6\n v_add_f32 %2, %2, %7\n v_add_f32 %3, %3, %7\n"
-#elif APT_T_EXTRA == 2 // 16 min (half-rate class)
-#define APT_T_OPS "v_min_f32 %0, %0, %6\n v_min_f32 %1, %1, %6\n v_min_f32 %2, %2, %7\n v_min_f32 %3, %3, %7\n"
-#elif APT_T_EXTRA == 3 // 8 packed
-#define APT_T_OPS "v_pk_add_f32 %4, %4, %5\n v_pk_mul_f32 %5, %5, %4\n"
-#else                  // 4 transcendental
-#define APT_T_OPS "v_rsq_f32 %0, %0\n"
-#endif
-        asm volatile(APT_R4(APT_T_OPS) : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(y0), "+v"(y1) : "v"(dy), "v"(dz));
-    }
-#endif
     auto update_keys = [&](uint32_t m0, uint32_t m1, int k) {
         const uint32_t nb = min3_u32(best, m0, m1);
         const uint64_t better = __builtin_amdgcn_ballot_w64(nb != best); // strict '<': lowest index wins ties
@@ -356,9 +300,7 @@ __device__ __forceinline__ Hit8 intersect_ns8_v2(const Scene8 &sc, float ox, flo
         b2 = (k & 4) ? (b2 | better) : (b2 & ~better);
         if (MODE == kModeOracle) any |= better;
     };
-    auto update = [&](float t0, float t1, int k) { update_keys(f32_bits(t0) - kc.bias, f32_bits(t1) - kc.bias, k); };
     auto update64 = [&](uint64_t keys, int k) { update_keys((uint32_t)keys, (uint32_t)(keys >> 32), k); };
-    (void)update; (void)update64;
     HitPre2 hp[4];
     if (PLANES) intersect_pre_planes(sc, ox, oy, oz, dx, dy, dz, hp);
 #pragma unroll
@@ -372,7 +314,6 @@ __device__ __forceinline__ Hit8 intersect_ns8_v2(const Scene8 &sc, float ox, flo
         const f2 y = h.disc * r0, hh = r0 * 0.5f;
         const f2 res = __builtin_elementwise_fma(-y, y, h.disc);
         const f2 q = __builtin_elementwise_fma(res, hh, y);
-#if APT_KEY64
         // Both keys of a sphere by ONE 64-bit add of (2^31 - bias, -bias) to its (-t0, t1) register pair (u(x) = bit pattern).
         // Low half: u(-t0) + 2^31 - bias (mod 2^32) is key(t0) = u(t0) - bias when t0 > eps (u(-t0) = 2^31 + u(t0)); for every other
         // t0 -- negative: u(|t0|) + 2^31 - bias; in [+0, eps]: 2^32 - (bias - u(t0)); NaN, inf -- it is >= key(kMissT), like the
@@ -382,11 +323,6 @@ __device__ __forceinline__ Hit8 intersect_ns8_v2(const Scene8 &sc, float ox, flo
         // `best` therefore only ever holds a true key or the initial one, and tmin = value(best) as before.
         update64(root_pair<0>(h.b, q) + kc.nbias2, k);
         update64(root_pair<1>(h.b, q) + kc.nbias2, k + 1);
-#else
-        const f2 t0 = h.b - q, t1 = h.b + q;
-        update(t0.x, t1.x, k);
-        update(t0.y, t1.y, k + 1);
-#endif
     }
     const float tmin = bits_f32(best + kc.bias);
     uint64_t light_mask; // lanes whose arg-min is the light
@@ -637,7 +573,7 @@ __device__ __forceinline__ void bounce_ns8_checked(const Scene8 &sc, const Tab8 
         const bool lane = select_const(redo & active, 1) != 0 && (!fast_ok || !path_finished(cold));
         if (__any(lane)) {
             asm volatile("" ::: "memory");
-            (void)bounce_ns8<MODE, false>(sc, tab, cold, n, ta);
+            bounce_ns8_exact<MODE>(sc, tab, cold, n, ta);
             alive = __builtin_amdgcn_ballot_w64(n.alive != 0);
             fast_stands = false;
             if (ta.traced && (threadIdx.x & 63) == 0) atomicAdd(ta.traced + 3, 1ull); // statistics: exact re-runs
@@ -685,7 +621,7 @@ __device__ __forceinline__ uint32_t trace_ns8(const Scene8 &sc, const Tab8 tab, 
             from.rxy = rxy; from.rz = rz;
             for (; d < ta.depth; ++d) {
                 PathState n;
-                (void)bounce_ns8<MODE, false>(sc, tab, from, n, ta);
+                bounce_ns8_exact<MODE>(sc, tab, from, n, ta);
                 if (ta.rr_start && d + 1 >= ta.rr_start) russian_roulette(n, rr_key, d);
                 from = n;
             }
@@ -900,7 +836,7 @@ __device__ __forceinline__ void grid_segment(const GridCtx &ctx, PathState &s, b
         const float t = select_root(hp.b - q, hp.b + q, ta.eps);
         if (t < tmin || (t == tmin && (int)k < idx)) { tmin = t; idx = (int)k; }
     };
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(APT_GRID_HEADER_VMEM)
+#if defined(__HIP_DEVICE_COMPILE__)
     if (grid_ok && h.off_cellslot) {
         // The always-tested list from its pair slots, by explicit SCALAR loads (wave-uniform data the compiler would fetch with vector
         // loads and a wait each, like the header: load_grid_header): two spheres and their ids per pair of loads.
@@ -1054,12 +990,8 @@ __device__ __forceinline__ GridHeader load_grid_header(const uint32_t *grid) {
 template <int MODE, bool RETIRE>
 __device__ __forceinline__ uint32_t trace_grid(const float *__restrict__ sph, const uint32_t *__restrict__ grid,
                                                PathState &s, bool valid, const TraceArgs &ta, uint64_t path) {
-#ifdef APT_GRID_HEADER_VMEM
-    const GridCtx gc{reinterpret_cast<const GridHeader *>(grid), sph, grid, &ta};
-#else
     const GridHeader hdr = load_grid_header(grid);
     const GridCtx gc{&hdr, sph, grid, &ta};
-#endif
     const uint64_t rr_key = ta.rr_start ? rr_path_key(ta.seed, path) : 0;
     uint32_t traced = 0, n_cells = 0, n_tests = 0; // statistics
     for (uint32_t d = 0; d < ta.depth; ++d) {

@@ -14,10 +14,6 @@
 #pragma once
 #include "pt_trace.h"
 
-#ifndef APT_TWO_INLOOP_EXACT
-#define APT_TWO_INLOOP_EXACT 1
-#endif
-
 namespace {
 
 struct PathPair { // .x = path A, .y = path B
@@ -142,11 +138,11 @@ __device__ __forceinline__ void trace2_ns8_t(const Scene8 &sc, const Tab8 tab, P
     uint32_t ones_off = 8 * 16; // the entry after the 8 albedos (load_scene8 writes it)
     asm volatile("" : "+v"(ones_off));
     uint64_t aliveA = __builtin_amdgcn_ballot_w64(true), aliveB = aliveA;
-#if APT_TWO_INLOOP_EXACT
-    // Round 3 form: the exact form of a bounce is a COLD BLOCK INSIDE the loop (the wave redoes that one bounce of both paths
+    // The exact form of a bounce is a COLD BLOCK INSIDE the loop (the wave redoes that one bounce of both paths
     // with sqrtf() and '/', writes the same registers, and goes on with fast bounces).  The loop then has no exits besides its
     // end -- the round-2 form left the loop for a "rest of the path, exact" tail, and every such exit edge kept the state of
-    // both ping-pong halves alive across the back edge.
+    // both ping-pong halves alive across the back edge.  (Four bounces per turn -- half as many back-edge copies -- measured in
+    // round 3: C2 20.40 against 19.95 ms, the longer body costs the ray-generate part more registers than the copies cost; not kept.)
     const bool fast_ok = eps_allows_rootkey(ta.eps);
     auto step = [&](const PathPair &in, PathPair &out) __attribute__((always_inline)) {
         uint64_t oa = aliveA, ob = aliveB;
@@ -164,8 +160,8 @@ __device__ __forceinline__ void trace2_ns8_t(const Scene8 &sc, const Tab8 tab, P
         }
         if (__builtin_expect(redo_any, 0)) {
             PathState a = unpack_path(in, 0, aliveA), b = unpack_path(in, 1, aliveB), na, nb;
-            (void)bounce_ns8<MODE, false>(sc, tab, a, na, ta);
-            (void)bounce_ns8<MODE, false>(sc, tab, b, nb, ta);
+            bounce_ns8_exact<MODE>(sc, tab, a, na, ta);
+            bounce_ns8_exact<MODE>(sc, tab, b, nb, ta);
             out.ox = f2{na.oxy.x, nb.oxy.x}; out.oy = f2{na.oxy.y, nb.oxy.y}; out.oz = f2{na.oz, nb.oz};
             out.dx = f2{na.dxy.x, nb.dxy.x}; out.dy = f2{na.dxy.y, nb.dxy.y}; out.dz = f2{na.dz, nb.dz};
             out.rx = f2{na.rxy.x, nb.rxy.x}; out.ry = f2{na.rxy.y, nb.rxy.y}; out.rz = f2{na.rz, nb.rz};
@@ -186,46 +182,6 @@ __device__ __forceinline__ void trace2_ns8_t(const Scene8 &sc, const Tab8 tab, P
         s = n;
     }
 }
-#else
-    auto rest_exact = [&](const PathPair &from, uint32_t d0) __attribute__((always_inline)) { // -> result in s
-        PathState a = unpack_path(from, 0, aliveA), b = unpack_path(from, 1, aliveB);
-        for (uint32_t d = d0; d < ta.depth; ++d) {
-            PathState na, nb;
-            (void)bounce_ns8<MODE, false>(sc, tab, a, na, ta);
-            (void)bounce_ns8<MODE, false>(sc, tab, b, nb, ta);
-            a = na; b = nb;
-        }
-        if (ta.traced && (threadIdx.x & 63) == 0) atomicAdd(ta.traced + 3, 1ull); // statistics: waves that left the fast loop
-        s.rx = f2{a.rxy.x, b.rxy.x}; s.ry = f2{a.rxy.y, b.rxy.y}; s.rz = f2{a.rz, b.rz};
-    };
-    auto step = [&](const PathPair &in, PathPair &out) __attribute__((always_inline)) -> bool { // true: the wave must go exact from `in`
-        uint64_t oa = aliveA, ob = aliveB, redoA, redoB;
-        bounce2_ns8<MODE, PLANES>(sc, tab, in, out, ta, kc, ones_off, oa, ob, redoA, redoB);
-        if (__builtin_expect((redoA | redoB) != 0, 0)) {
-            // the request of a path that is already finished (alive bit cleared or throughput zero) is ignored: it cannot
-            // reach any output any more (deep all-miss paths, |n| ~ 1e20, are of that kind)
-            const bool finA = select_const(aliveA, 1) == 0 || (in.rx.x == 0.0f && in.ry.x == 0.0f && in.rz.x == 0.0f);
-            const bool finB = select_const(aliveB, 1) == 0 || (in.rx.y == 0.0f && in.ry.y == 0.0f && in.rz.y == 0.0f);
-            if (__any((select_const(redoA, 1) != 0 && !finA) || (select_const(redoB, 1) != 0 && !finB))) return true;
-        }
-        aliveA = oa; aliveB = ob;
-        return false;
-    };
-    if (__builtin_expect(!eps_allows_rootkey(ta.eps), 0)) { rest_exact(s, 0); return; }
-    PathPair n;
-    uint32_t d = 0;
-    // (Four bounces per turn -- half as many back-edge copies -- measured in round 3: C2 20.40 against 19.95 ms, the longer body
-    // costs the ray-generate part more registers than the copies cost; not kept.)
-    for (; d + 2 <= ta.depth; d += 2) { // render.cpp:140-188
-        if (__builtin_expect(step(s, n), 0)) { rest_exact(s, d); return; }
-        if (__builtin_expect(step(n, s), 0)) { rest_exact(n, d + 1); return; }
-    }
-    if (d < ta.depth) {
-        if (__builtin_expect(step(s, n), 0)) { rest_exact(s, d); return; }
-        s = n;
-    }
-}
-#endif
 
 // `planes`: scene8_shares_planes(sc), evaluated once per wave by the kernel (wave-uniform branch around two copies of the loop)
 template <int MODE>
