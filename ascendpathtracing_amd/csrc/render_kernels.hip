@@ -236,7 +236,9 @@ int do_render_frame(const Launch &ls, const apt_render_params *p, void *stream, 
         const dim3 qgrid((unsigned)waves), qblock(64);
         // APT_FLAG_GRID_SLOTS: the caller vouches for the grid (apt_grid_flags): this launch is the frame's only one, and a grid that does not
         // keep the promise is reported through the status word (grid_walk == 3 tells the kernel to report instead of returning silently)
-        const bool vouched = (p->flags & APT_FLAG_GRID_SLOTS) && eps_allows_rootkey(p->eps);
+        // (Only with a status word to report through: without one -- a context's first launch inside a stream capture, a device index beyond
+        // the context's table -- a grid that breaks the promise would render nothing and say nothing, so the two-launch form is kept then.)
+        const bool vouched = (p->flags & APT_FLAG_GRID_SLOTS) && eps_allows_rootkey(p->eps) && ta.status != nullptr;
         TraceArgs ta_q = ta;
         ta_q.grid_walk = vouched ? 3u : 0u;
 #define APT_LAUNCH_GRID_QUEUE(M, R, S) hipLaunchKernelGGL((render_frame_queue8_kernel<M, R, kSceneGrid, S>), qgrid, qblock, qlds, st, spheres, fa, ta_q, lp, qa)

@@ -110,6 +110,10 @@ class FrameShard:
         that read it has completed.  Other ranks wait for their collective on the current stream in finish(); the root waits for it
         on its side stream only, so without this the render of frame k could overwrite the buffer the gather of frame k - slots is
         still sending from."""
+        # A gather of this very slot that is still PENDING (gather_async without its finish(): slots=1, or a render into the slot
+        # whose gather was the last one issued) has recorded no event yet -- finish it first, which does (ADVICE r5).
+        if self._pending is not None and (slot is None or self._pending[1] == slot):
+            self.finish()
         for k in ([slot] if slot is not None else list(self._sent)):
             ev = self._sent.pop(k, None)
             if ev is not None:

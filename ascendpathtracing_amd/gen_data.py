@@ -7,7 +7,7 @@ import os
 
 import numpy as np
 
-from ._lib import check, lib
+from ._lib import AptError, check, lib
 
 width, height, samples = 16, 16, 1      # gen_data.py:6-8
 eps, bounceMax = 1e-4, 5                # gen_data.py:9-10
@@ -115,11 +115,19 @@ def grid_flags(grid, num_spheres):
     """apt_grid_flags: the flags a built grid earns for a scene of `num_spheres` spheres (APT_FLAG_GRID_SLOTS: one launch per
     frame instead of two) -- `grid` is build_grid()'s numpy buffer or build_grid_device()'s tensor (its 128-byte head is copied
     to the host: a set-up step, not part of a launch path).  OR the result into RenderParams.flags next to accel."""
+    # the header is 128 BYTES whatever the element type of the buffer the caller holds it in (apt_grid_flags reads that many)
     if hasattr(grid, "data_ptr"):
-        head = grid[:32].cpu().numpy()
+        flat = grid.reshape(-1)
+        if flat.numel() * flat.element_size() < 128:
+            raise AptError("grid_flags: the buffer is shorter than a grid header (128 bytes)")
+        n = (128 + flat.element_size() - 1) // flat.element_size()
+        head = flat[:n].cpu().contiguous().numpy().view(np.uint8)[:128]
     else:
-        head = np.ascontiguousarray(grid[:32])
-    head = np.ascontiguousarray(head.view(np.uint32))
+        flat = np.ascontiguousarray(grid).reshape(-1)
+        if flat.nbytes < 128:
+            raise AptError("grid_flags: the buffer is shorter than a grid header (128 bytes)")
+        head = flat.view(np.uint8)[:128]
+    head = np.ascontiguousarray(head)
     lib().apt_grid_flags.restype = ctypes.c_uint32
     return int(lib().apt_grid_flags(head.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint32(num_spheres)))
 

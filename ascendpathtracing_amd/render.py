@@ -370,15 +370,17 @@ def render_reference_frame_fused(w, h, s, depth=5, seed=0, spheres=None, mode=No
     # kernel runs on (a caller's side stream included), so the upload is ordered before the launch and the caching allocator does not
     # hand the table to another stream while the kernel still reads it (the cross-stream lifetime hazard fixed for
     # render_reference_frame in round 3).
-    tstream = torch.cuda.current_stream() if stream is None else (torch.cuda.ExternalStream(stream) if isinstance(stream, int) else stream)
+    caller = torch.cuda.current_stream()    # the stream a caller's own table was uploaded on (read BEFORE the `with` below changes it)
+    tstream = caller if stream is None else (torch.cuda.ExternalStream(stream) if isinstance(stream, int) else stream)
     with torch.cuda.stream(tstream):
         if checkpoints is None:
             ck, g_lo = mt_group_checkpoints(w, h, s, seed, pixel_begin, pixel_count, mt_state)
             checkpoints = (torch.from_numpy(ck.view(np.int32)).cuda(), g_lo)
         else:
-            # a caller's table, made on whatever stream was current then: this launch must come after its upload (ordering) and the
-            # allocator must not recycle it before the launch is through (lifetime) -- both matter when `stream` is a side stream
-            tstream.wait_stream(torch.cuda.current_stream())
+            # a caller's table, made on the caller's current stream: this launch must come after its upload (ordering) and the
+            # allocator must not recycle it before the launch is through (lifetime) -- both matter when `stream` is a side stream.
+            # (Round 5 waited on torch.cuda.current_stream() INSIDE the `with`: that is tstream itself, a wait on nothing.)
+            tstream.wait_stream(caller)
         ck_d, g_lo = checkpoints
         ck_d.record_stream(tstream)
         p = make_params(w, h, s, depth=depth, mode=APT_MODE_ORACLE if mode is None else mode, flags=flags)

@@ -306,10 +306,16 @@ HEADLINE_KERNEL = "render_frame_kernel<0, 0, 8, false, true>"      # K-mode, 8-s
 
 
 def traffic_probe():
-    """`bench.py --traffic-probe`: what measure_traffic() wraps in rocprofv3 -- the headline launch (C2, K-mode, every segment traced)
-    a few times, nothing else (no oracle, no timing, no output)."""
+    """`bench.py --traffic-probe`: what measure_counters() wraps in rocprofv3 -- the headline launch (C2, K-mode, every segment traced)
+    a few times, nothing else (no oracle, no timing, no output).  This process runs UNDER the profiler, whose preloaded library has
+    initialised the GPU before main() starts: it must not spawn anything (a child would inherit the preload; make's recipe shells exec
+    hipcc, and an exec in a process that holds the GPU takes the machine down on this pool -- ADVICE r5).  So it never builds: the
+    un-profiled parent has, and a stale library is an error here."""
     import __graft_entry__
-    __graft_entry__.build()
+    if not __graft_entry__._is_current():
+        print("bench.py --traffic-probe: the in-tree library is missing or older than its sources; build it first "
+              "(python __graft_entry__.py) -- the probe itself never builds", file=sys.stderr)
+        sys.exit(3)
     import torch
     import ascendpathtracing_amd as apt
     from ascendpathtracing_amd import gen_data, render
@@ -323,16 +329,56 @@ def traffic_probe():
     torch.cuda.synchronize()
 
 
-def measure_traffic(timeout_s=150):
-    """roofline.traffic measured IN THIS RUN (it used to be replayed from a committed file): HBM bytes per launch of the
-    headline kernel from two rocprofv3 passes -- `--pmc FETCH_SIZE` and `--pmc WRITE_SIZE`, each with --kernel-trace only, as
-    MI355X_MICROARCH.md's HBM section prescribes (separate passes; values in KiB; FETCH_SIZE doubled on gfx950) -- of
-    `python3 bench.py --traffic-probe`, run as CHILD processes before this process has touched the GPU (bench.py cannot wrap itself).
-    -> dict for the roofline block, or {"error": ...} (no rocprofv3, a pass failed, already under a profiler): the caller then falls
-    back to the committed figure of this very build, or null."""
+# The counter passes of the live roofline block: one rocprofv3 child process each (MI355X_MICROARCH.md: counters in their own passes, with
+# --kernel-trace only).  The third is the VALU side north_star asks for ("achieved HBM GB/s and VALU occupancy").
+PMC_PASSES = (("FETCH_SIZE",), ("WRITE_SIZE",),
+              ("SQ_WAVES", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU", "GRBM_GUI_ACTIVE"))
+N_SIMD, N_XCD = 1024, 8                       # MI355X: 256 CUs x 4 SIMDs; GRBM_GUI_ACTIVE is summed over the 8 XCDs
+
+
+def counter_rows(out_dir, kernel=None):
+    """{counter: [value per launch]}, [duration ns per launch] of the launches of `kernel` in a rocprofv3 --output-format csv directory.
+    Launches are matched between the counter file and the trace by dispatch id; the FIRST launch of the process is dropped from both
+    (it carries the write-back of the zero-filled buffers and the code-object load: profiles/summarize.py does the same)."""
     import csv
     import glob
+    kernel = HEADLINE_KERNEL if kernel is None else kernel
+    vals, dur = {}, {}
+    for f in sorted(glob.glob(os.path.join(out_dir, "**", "*_counter_collection.csv"), recursive=True)):
+        for row in csv.DictReader(open(f)):
+            if kernel in row["Kernel_Name"]:       # (rows of one dispatch and counter -- instances, if the tool splits them -- add up)
+                d = vals.setdefault(row["Counter_Name"], {})
+                k = int(row.get("Dispatch_Id", 0) or len(d) + 1)
+                d[k] = d.get(k, 0.0) + float(row["Counter_Value"])
+    for f in sorted(glob.glob(os.path.join(out_dir, "**", "*_kernel_trace.csv"), recursive=True)):
+        for row in csv.DictReader(open(f)):
+            if kernel in row["Kernel_Name"]:
+                dur[int(row.get("Dispatch_Id", 0) or len(dur) + 1)] = float(row["End_Timestamp"]) - float(row["Start_Timestamp"])
+    steady = lambda d: [v for _, v in sorted(d.items())][1:] if len(d) > 1 else list(d.values())     # noqa: E731
+    return {k: steady(v) for k, v in vals.items()}, steady(dur)
+
+
+def derive_valu(avg, kernel_ns, segments):
+    """The VALU side of the roofline from the per-launch averages of PMC_PASSES[2] (formulas of profiles/summarize.py, which writes
+    profiles/rNN_pmc.json from the committed passes: the two must agree)."""
+    cyc = avg["GRBM_GUI_ACTIVE"] / N_XCD                          # shader cycles of the launch
+    out = {"valu_insts_per_simd_cycle": round(avg["SQ_INSTS_VALU"] / (cyc * N_SIMD), 4),
+           "waves_per_simd": round(avg["SQ_WAVE_CYCLES"] * 4 / (cyc * N_SIMD), 3),          # SQ_WAVE_CYCLES counts quad-cycles
+           "valu_insts_per_segment": round(avg["SQ_INSTS_VALU"] * 64 / segments, 2),           # wave-level instructions x 64 lanes / lane-segments
+           "effective_clock_ghz": round(cyc / kernel_ns, 3)}
+    if "SQ_THREAD_CYCLES_VALU" in avg and avg.get("SQ_ACTIVE_INST_VALU"):
+        out["lane_activity"] = round(avg["SQ_THREAD_CYCLES_VALU"] / (avg["SQ_ACTIVE_INST_VALU"] * 64), 4)
+    return out
+
+
+def measure_counters(timeout_s=150):
+    """The roofline block's counters measured IN THIS RUN: HBM bytes per launch of the headline kernel (`--pmc FETCH_SIZE`, `--pmc WRITE_SIZE`:
+    separate passes, KiB, FETCH_SIZE doubled on gfx950, as MI355X_MICROARCH.md's HBM section prescribes) and its VALU issue rate, resident
+    waves and lane activity (a third pass), each pass `rocprofv3 --kernel-trace --pmc ... -- python3 bench.py --traffic-probe` as a CHILD
+    process before this process has touched the GPU (bench.py cannot wrap itself).  -> dict for the roofline block; a pass that fails
+    leaves its keys out and says why under "<what>_probe_error" (no rocprofv3, a pass failed, already under a profiler)."""
     import shutil
+    import signal
     import subprocess
     import tempfile
     if any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
@@ -340,37 +386,66 @@ def measure_traffic(timeout_s=150):
     tool = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
     if tool is None:
         return {"error": "rocprofv3 not found"}
-    res, tmp = {}, tempfile.mkdtemp(prefix="apt_traffic_", dir="/tmp")
+    tmp = tempfile.mkdtemp(prefix="apt_pmc_", dir="/tmp")
     env = dict(os.environ, TMPDIR="/tmp")
+    avg, launches, probe_ns, errors = {}, {}, {}, {}
     try:
-        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
-            out = os.path.join(tmp, ctr)
-            cmd = [tool, "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", out, "--",
+        for group in PMC_PASSES:
+            out = os.path.join(tmp, group[0])
+            cmd = [tool, "--kernel-trace", "--pmc", *group, "--output-format", "csv", "-d", out, "--",
                    sys.executable, os.path.abspath(__file__), "--traffic-probe"]
-            r = subprocess.run(cmd, env=env, cwd="/tmp", stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=timeout_s)
-            if r.returncode != 0:
-                return {"error": f"rocprofv3 --pmc {ctr} exited {r.returncode}: {r.stderr.decode(errors='replace')[-200:]}"}
-            vals, dur = [], []
-            for f in glob.glob(os.path.join(out, "**", "*_counter_collection.csv"), recursive=True):
-                for row in csv.DictReader(open(f)):
-                    if HEADLINE_KERNEL in row["Kernel_Name"] and row["Counter_Name"] == ctr:
-                        vals.append(float(row["Counter_Value"]))
-            for f in glob.glob(os.path.join(out, "**", "*_kernel_trace.csv"), recursive=True):
-                for row in csv.DictReader(open(f)):
-                    if HEADLINE_KERNEL in row["Kernel_Name"]:
-                        dur.append(float(row["End_Timestamp"]) - float(row["Start_Timestamp"]))
-            if not vals:
-                return {"error": f"no {ctr} rows for {HEADLINE_KERNEL}"}
-            res[ctr] = (sum(vals) / len(vals) * 1024.0, len(vals), sum(dur) / max(1, len(dur)) / 1e6)
-    except (OSError, subprocess.SubprocessError, KeyError, ValueError) as e:
-        return {"error": repr(e)[:200]}
+            what = "traffic" if group[0] in ("FETCH_SIZE", "WRITE_SIZE") else "valu"
+            try:
+                # own session: on a timeout the WHOLE group dies -- rocprofv3 and the probe's python underneath it, which would otherwise
+                # keep rendering on the GPU while the parent times its steps
+                proc = subprocess.Popen(cmd, env=env, cwd="/tmp", stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, start_new_session=True)
+                try:
+                    _, err = proc.communicate(timeout=timeout_s)
+                except subprocess.TimeoutExpired:
+                    try:
+                        os.killpg(proc.pid, signal.SIGKILL)
+                    except OSError:
+                        pass
+                    proc.communicate()
+                    errors[what] = f"rocprofv3 --pmc {' '.join(group)} timed out after {timeout_s} s (process group killed)"
+                    continue
+                if proc.returncode != 0:
+                    errors[what] = f"rocprofv3 --pmc {' '.join(group)} exited {proc.returncode}: {err.decode(errors='replace')[-200:]}"
+                    continue
+                vals, dur = counter_rows(out)
+                missing = [c for c in group if not vals.get(c)]
+                if missing:
+                    errors[what] = f"no {missing} rows for {HEADLINE_KERNEL}"
+                    continue
+                for c in group:
+                    avg[c] = sum(vals[c]) / len(vals[c])
+                    launches[c] = len(vals[c])
+                probe_ns[group[0]] = sum(dur) / max(1, len(dur))
+            except (OSError, subprocess.SubprocessError, KeyError, ValueError) as e:
+                errors[what] = repr(e)[:200]
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
-    fetch, write = 2.0 * res["FETCH_SIZE"][0], res["WRITE_SIZE"][0]
-    return {"traffic": round(fetch + write), "traffic_fetch_bytes_x2": round(fetch), "traffic_write_bytes": round(write),
-            "traffic_launches_averaged": res["WRITE_SIZE"][1], "traffic_probe_kernel_ms": round(res["WRITE_SIZE"][2], 3),
-            "traffic_source": "measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, KiB, "
-                              "FETCH_SIZE x2 on gfx950) of `bench.py --traffic-probe` as child processes"}
+    res = {}
+    if "FETCH_SIZE" in avg and "WRITE_SIZE" in avg:
+        fetch, write = 2.0 * avg["FETCH_SIZE"] * 1024.0, avg["WRITE_SIZE"] * 1024.0
+        res.update({"traffic": round(fetch + write), "traffic_fetch_bytes_x2": round(fetch), "traffic_write_bytes": round(write),
+                    "traffic_launches_averaged": launches["WRITE_SIZE"], "traffic_probe_kernel_ms": round(probe_ns["WRITE_SIZE"] / 1e6, 3),
+                    "traffic_source": "measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, KiB, "
+                                      "FETCH_SIZE x2 on gfx950) of `bench.py --traffic-probe` as child processes, first launch dropped"})
+    elif "traffic" in errors:
+        res["traffic_probe_error"] = errors["traffic"]
+    if all(c in avg for c in ("GRBM_GUI_ACTIVE", "SQ_INSTS_VALU", "SQ_WAVE_CYCLES")):
+        seg = C2["w"] * C2["h"] * 4 * C2["s"] * C2["depth"]
+        res.update(derive_valu(avg, probe_ns[PMC_PASSES[2][0]], seg))
+        res["valu_probe_kernel_ms"] = round(probe_ns[PMC_PASSES[2][0]] / 1e6, 3)
+        res["valu_launches_averaged"] = launches["SQ_INSTS_VALU"]
+        res["valu_source"] = ("measured in this run: rocprofv3 --kernel-trace --pmc " + " ".join(PMC_PASSES[2]) + " of `bench.py --traffic-probe`; "
+                              "valu_insts_per_simd_cycle = SQ_INSTS_VALU / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs) against ~0.238 issuable for this instruction "
+                              "mix (profiles/microbench/issue_model_mi355x.txt); waves_per_simd = SQ_WAVE_CYCLES x 4 / the same cycles; "
+                              "lane_activity = SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU)")
+    elif "valu" in errors:
+        res["valu_probe_error"] = errors["valu"]
+    return res
 
 
 def self_launch(n):
@@ -402,8 +477,8 @@ def main():
     ap.add_argument("--stripes", type=int, default=1, help="interleaved stripes per rank (N > 1; see dist.py)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
-    ap.add_argument("--no-traffic-probe", action="store_true", help="do not measure roofline.traffic with rocprofv3 child processes (N = 1)")
-    ap.add_argument("--traffic-probe", action="store_true", help="internal: the launches measure_traffic() profiles")
+    ap.add_argument("--no-traffic-probe", action="store_true", help="do not measure roofline.traffic / the VALU counters with rocprofv3 child processes (N = 1)")
+    ap.add_argument("--traffic-probe", action="store_true", help="internal: the launches measure_counters() profiles")
     ap.add_argument("--dry-run", action="store_true",
                     help="control-flow rehearsal without a GPU (tests/test_bench_dry_run.py): gloo, CPU tensors, a tiny frame and NO "
                          "render at all (the launch is a no-op) -- exercises the rendezvous, sharding, double-buffered gather, "
@@ -420,7 +495,7 @@ def main():
 
     live = None
     if args.gpus == 1 and "WORLD_SIZE" not in os.environ and args.workload in ("auto", "c2") and not args.no_traffic_probe:
-        live = measure_traffic()              # child processes (they find the library built); this process has not touched the GPU yet
+        live = measure_counters()             # child processes (they find the library built); this process has not touched the GPU yet
 
     import torch
     import torch.distributed as dist
@@ -511,13 +586,17 @@ def main():
     if workload != "c2" or world != 1:
         traffic, traffic_tag = None, None     # the committed PMC passes are of the N = 1 C2 launch
     traffic_extra = {}
-    if live is not None and "traffic" in live:   # measured in this very run: that is the figure
-        traffic, traffic_tag = live["traffic"], None
+    if live is not None:                      # measured in this very run: those are the figures
         traffic_extra = {k: v for k, v in live.items() if k != "traffic"}
-        traffic_extra["traffic_over_algorithmic"] = round(live["traffic"] / (W * H * 15 + 512), 4)
-    elif live is not None:
-        traffic_extra = {"traffic_probe_error": live.get("error"),
-                         "traffic_source": "profiles/hbm_traffic.json (committed PMC passes of this build)" if traffic is not None else None}
+        if "traffic" in live:
+            traffic, traffic_tag = live["traffic"], None
+            traffic_extra["traffic_over_algorithmic"] = round(live["traffic"] / (W * H * 15 + 512), 4)
+            traffic_extra["hbm_gbps"] = round(live["traffic"] / (kern_ms * 1e-3) / 1e9, 3)       # achieved HBM rate of the headline kernel (peak ~8000)
+        else:
+            traffic_extra.setdefault("traffic_probe_error", live.get("error"))
+            traffic_extra["traffic_source"] = "profiles/hbm_traffic.json (committed PMC passes of this build)" if traffic is not None else None
+        if "valu_insts_per_simd_cycle" not in live:
+            traffic_extra.setdefault("valu_probe_error", live.get("error"))
     names = {"c2": f"C2: gen_spheres() 8-sphere scene, {W}x{H}, S={S} ({4 * S} spp), depth {D}",
              "c3": f"C3: gen_spheres() 8-sphere scene, {W}x{H}, S={S} ({4 * S} spp), depth {D}, strong-sharded over {world} rank(s): "
                    f"contiguous pixel bands (dist.split_range), {shard.pixel_count} pixels per rank",

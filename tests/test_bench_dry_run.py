@@ -71,40 +71,107 @@ def _fake_rocprofv3(tmp_path, body):
     return str(tmp_path)
 
 
-def test_live_traffic_probe_parses_rocprofv3_output_and_degrades_gracefully(tmp_path, monkeypatch):
-    """bench.py measures roofline.traffic in the same run by wrapping `bench.py --traffic-probe` in two rocprofv3
-    counter passes.  Here rocprofv3 is a stand-in script (no GPU): the KiB -> bytes conversion, the gfx950 doubling of FETCH_SIZE,
-    the kernel filter and the averaging are checked on known numbers; a failing profiler, a missing one and a run that is already
-    being profiled give {"error": ...} (bench.py then falls back to the committed figure of the same build, or null) -- never an exception."""
+def test_live_counter_probe_parses_rocprofv3_output_and_degrades_gracefully(tmp_path, monkeypatch):
+    """bench.py measures roofline.traffic AND the VALU side of the roofline (north_star's "HBM GB/s and VALU occupancy")
+    in the same run by wrapping `bench.py --traffic-probe` in three rocprofv3 counter passes.  Here rocprofv3 is a stand-in script (no
+    GPU): the KiB -> bytes conversion, the gfx950 doubling of FETCH_SIZE, the kernel filter, dropping the process's first launch, the
+    averaging and the derived VALU figures (profiles/summarize.py's formulas) are checked on known numbers; a failing profiler, a missing
+    one and a run that is already being profiled give error entries (bench.py then falls back to the committed traffic figure of the same
+    build, or null) -- never an exception."""
     import bench
     for k in [k for k in os.environ if k.startswith(("ROCPROF", "ROCP_"))]:
         monkeypatch.delenv(k)
     body = r'''
 import os, sys
 a = sys.argv
-out, ctr = a[a.index("-d") + 1], a[a.index("--pmc") + 1]
+out = a[a.index("-d") + 1]
+ctrs = a[a.index("--pmc") + 1:a.index("--output-format")]
 assert "--kernel-trace" in a and a[a.index("--") + 1:][1].endswith("bench.py") and a[-1] == "--traffic-probe"
 os.makedirs(out + "/host/", exist_ok=True)
 k = "void (anonymous namespace)::render_frame_kernel<0, 0, 8, false, true>(float const*, ...)"
 other = "void (anonymous namespace)::render_frame_kernel<1, 0, 8, false, true>(float const*, ...)"
-vals = {"FETCH_SIZE": [400.0, 600.0], "WRITE_SIZE": [30000.0, 31000.0]}[ctr]
+# per launch (dispatch ids 1..3; the FIRST is the process's first launch and must be dropped)
+table = {"FETCH_SIZE": [90000.0, 400.0, 600.0], "WRITE_SIZE": [110000.0, 30000.0, 31000.0],
+         "GRBM_GUI_ACTIVE": [9e9, 8 * 40e6, 8 * 40e6],              # 40e6 shader cycles per launch (summed over 8 XCDs)
+         "SQ_INSTS_VALU": [1.0, 0.25 * 40e6 * 1024, 0.25 * 40e6 * 1024],   # 0.25 per SIMD-cycle
+         "SQ_ACTIVE_INST_VALU": [1.0, 1e9, 1e9], "SQ_THREAD_CYCLES_VALU": [1.0, 48e9, 48e9],     # 48 of 64 lanes
+         "SQ_WAVE_CYCLES": [1.0, 40e6 * 1024, 40e6 * 1024],          # quad-cycles: 4 waves per SIMD
+         "SQ_WAVES": [1.0, 1e6, 1e6], "SQ_BUSY_CYCLES": [1.0, 2.0, 3.0]}
 with open(out + "/host/1_counter_collection.csv", "w") as f:
-    f.write("Kernel_Name,Counter_Name,Counter_Value\n")
-    for v in vals: f.write('"%s",%s,%f\n' % (k, ctr, v))
-    f.write('"%s",%s,%f\n' % (other, ctr, 1e9))
+    f.write("Dispatch_Id,Kernel_Name,Counter_Name,Counter_Value\n")
+    for c in ctrs:
+        for d, v in enumerate(table[c]): f.write('%d,"%s",%s,%f\n' % (d + 1, k, c, v))
+        f.write('9,"%s",%s,%f\n' % (other, c, 1e12))
 with open(out + "/host/1_kernel_trace.csv", "w") as f:
-    f.write("Kernel_Name,Start_Timestamp,End_Timestamp\n")
-    f.write('"%s",1000,20001000\n"%s",0,5\n' % (k, other))
+    f.write("Dispatch_Id,Kernel_Name,Start_Timestamp,End_Timestamp\n")
+    f.write('1,"%s",0,90000000\n2,"%s",1000,20001000\n3,"%s",1000,20001000\n9,"%s",0,5\n' % (k, k, k, other))
 '''
     monkeypatch.setenv("PATH", _fake_rocprofv3(tmp_path, body) + os.pathsep + os.environ["PATH"])
-    r = bench.measure_traffic(timeout_s=60)
+    r = bench.measure_counters(timeout_s=60)
     assert r["traffic_fetch_bytes_x2"] == 2 * 500 * 1024 and r["traffic_write_bytes"] == 30500 * 1024
     assert r["traffic"] == r["traffic_fetch_bytes_x2"] + r["traffic_write_bytes"] and r["traffic_launches_averaged"] == 2
     assert r["traffic_probe_kernel_ms"] == 20.0 and "measured in this run" in r["traffic_source"]
+    assert r["valu_insts_per_simd_cycle"] == 0.25 and r["waves_per_simd"] == 4.0 and r["lane_activity"] == 0.75
+    assert r["effective_clock_ghz"] == 2.0 and r["valu_launches_averaged"] == 2 and "SQ_INSTS_VALU" in r["valu_source"]
+    seg = 1920 * 1080 * 4 * 64 * 8
+    assert r["valu_insts_per_segment"] == round(0.25 * 40e6 * 1024 * 64 / seg, 2)
     bad = tmp_path / "bad"
     bad.mkdir()
     monkeypatch.setenv("PATH", _fake_rocprofv3(bad, "import sys\nsys.stderr.write('no device')\nsys.exit(3)\n") + os.pathsep + os.environ["PATH"])
-    r = bench.measure_traffic(timeout_s=60)
-    assert "exited 3" in r["error"] and "traffic" not in r
+    r = bench.measure_counters(timeout_s=60)
+    assert "exited 3" in r["traffic_probe_error"] and "exited 3" in r["valu_probe_error"] and "traffic" not in r and "waves_per_simd" not in r
+    # a pass that hangs: the whole process group is killed (the stand-in starts a grandchild that would outlive a plain kill of the tool)
+    hang = tmp_path / "hang"
+    hang.mkdir()
+    mark = tmp_path / "grandchild.pid"
+    monkeypatch.setenv("PATH", _fake_rocprofv3(hang, "import subprocess, sys, time\np = subprocess.Popen([sys.executable, '-c', 'import time; time.sleep(120)'])\n"
+                                                     f"open({str(mark)!r}, 'w').write(str(p.pid))\ntime.sleep(120)\n") + os.pathsep + os.environ["PATH"])
+    monkeypatch.setattr(bench, "PMC_PASSES", bench.PMC_PASSES[:1])
+    r = bench.measure_counters(timeout_s=3)
+    assert "timed out" in r["traffic_probe_error"]
+    pid = int(mark.read_text())
+    for _ in range(50):
+        try:
+            os.kill(pid, 0)
+        except ProcessLookupError:
+            break
+        # (a zombie still answers kill 0 until init reaps it: look at its state)
+        try:
+            if open(f"/proc/{pid}/stat").read().split(")")[1].split()[0] == "Z":
+                break
+        except OSError:
+            break
+        import time
+        time.sleep(0.1)
+    else:
+        raise AssertionError("the probe's grandchild survived the timeout")
     monkeypatch.setenv("ROCPROFILER_SOMETHING", "1")          # already under a profiler: no nested run
-    assert "profiler" in bench.measure_traffic()["error"]
+    assert "profiler" in bench.measure_counters()["error"]
+
+
+def test_traffic_probe_never_builds(tmp_path):
+    """ADVICE r5: `bench.py --traffic-probe` runs under rocprofv3 (the GPU is initialised before main() starts), so it must not spawn
+    make / hipcc.  With a library older than its sources it exits non-zero and says why; nothing is built."""
+    import shutil
+    root = tmp_path / "repo"
+    (root / "ascendpathtracing_amd" / "csrc").mkdir(parents=True)
+    for f in ("bench.py", "__graft_entry__.py"):
+        shutil.copy(os.path.join(ROOT, f), root / f)
+    r = subprocess.run([sys.executable, str(root / "bench.py"), "--traffic-probe"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 3 and "never builds" in r.stderr and not (root / ".build.lock").exists()
+
+
+def test_a_run_that_dies_says_why_on_the_json_line():
+    """bench.py:__main__ (round 5, 5e7ac92; VERDICT r5 item 4): a run that cannot go on -- here: no GPU in this container -- prints ONE
+    JSON line on stdout with "value": null and an "error", and exits non-zero."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible: this is the no-GPU failure path")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--no-traffic-probe", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode != 0
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["value"] is None and out["error"] and out["unit"] == "Mray/s" and out["n_gpus"] == 1

@@ -46,24 +46,27 @@ def _worker(rank, world, port, w, h, s, out_path, stripes=1):
     dist.destroy_process_group()
 
 
-def _worker_pipelined(rank, world, port, out_path, w=8, h=6, stripes=1):
+def _worker_pipelined(rank, world, port, out_path, w=8, h=6, stripes=1, nslots=2):
     """Three frames (different seeds) through the double-buffered asynchronous gather bench.py uses;
-    w*h need not divide by world*stripes (unequal shards travel in equally padded buffers)."""
+    w*h need not divide by world*stripes (unequal shards travel in equally padded buffers).  nslots=1: every render writes the buffer
+    whose gather is still pending -- begin() must finish that gather first."""
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import ascendpathtracing_amd as apt
     from ascendpathtracing_amd import dist as apt_dist, gen_data
     sph = torch.from_numpy(gen_data.gen_spheres())
-    shard = apt_dist.FrameShard(apt.make_params(w, h, 1, depth=3), rank, world, device="cpu", slots=2, stripes=stripes)
+    shard = apt_dist.FrameShard(apt.make_params(w, h, 1, depth=3), rank, world, device="cpu", slots=nslots, stripes=stripes)
     slots = shard.alloc_slots()
     frames = []
     full = None
     for k in range(3):
         p = apt.make_params(w, h, 1, depth=3, seed=k)
-        shard.render(slots[k % 2], sph, _oracle_render_fn, params=p, slot=k % 2)
+        shard.render(slots[k % nslots], sph, _oracle_render_fn, params=p, slot=k % nslots)
+        if nslots == 1:
+            assert shard._pending is None      # begin(slot) has finished the gather that was reading this buffer
         full = shard.alloc_full() if rank == 0 else (None, None)
-        shard.gather_async(k % 2, *full)      # also completes frame k-1
+        shard.gather_async(k % nslots, *full)      # also completes frame k-1
         frames.append(full)
     shard.finish()
     if rank == 0:
@@ -76,6 +79,19 @@ def _worker_pipelined(rank, world, port, out_path, w=8, h=6, stripes=1):
 def test_pipelined_async_gather(tmp_path, oracle):
     out = str(tmp_path / "frames.npz")
     mp.spawn(_worker_pipelined, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = np.load(out)
+    sph = oracle.gen_spheres()
+    for k in range(3):
+        fb, u8, _, _ = oracle.render_frame(oracle.make_params(8, 6, 1, depth=3, seed=k), sph)
+        assert np.array_equal(got[f"fb{k}"].view(np.uint32), fb.view(np.uint32)), k
+        assert np.array_equal(got[f"u8{k}"], u8)
+
+
+def test_a_render_into_the_slot_of_a_pending_gather_finishes_it_first(tmp_path, oracle):
+    """with slots=1 (or any render into the slot whose gather_async has not been finished) the render would overwrite a
+    buffer the collective is still sending from.  FrameShard.begin() now completes that gather before the slot is written."""
+    out = str(tmp_path / "frames.npz")
+    mp.spawn(_worker_pipelined, args=(2, _free_port(), out, 8, 6, 1, 1), nprocs=2, join=True)
     got = np.load(out)
     sph = oracle.gen_spheres()
     for k in range(3):
