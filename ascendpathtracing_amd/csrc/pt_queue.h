@@ -557,7 +557,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SC == kScene
     };
     // ---- SC == kSceneGrid: any scene through the grid's pair-slot tables, every lane at its own place of its own walk -----------
     // Why this form.  The nested walk of render_frame_kernel (pt_trace.h grid_segment) is bound by the CU's vector-memory ADDRESS
-    // path, not by arithmetic or latency: its TA is 90-96 % busy (profiles/r03_grid_ta_pmc.json), and a wave-level load costs that
+    // path, not by arithmetic or latency: its TA is 90-96 % busy (profiles/history/r03_grid_ta_pmc.json), and a wave-level load costs that
     // unit the same ~7 (dword) / ~17 (dwordx4) cycles whether 3 or 8 of its lanes are active (profiles/microbench/ta_rates.hip:
     // the cost only grows beyond ~8 lanes, by ~2.2 cycles per L1-missing lane).  The nested form issues ~320 such loads per wave
     // and segment, its float4 candidate loads serving 3.5 lanes on average: the inner loop runs to the longest list of the wave in

@@ -354,7 +354,7 @@ __device__ __forceinline__ uint64_t bounce_ns8_v2(const Scene8 &sc, const Tab8 t
     // GenerateNewRays (rt_helper.h:504-709), as shade_and_reflect<MODE, true>, with the x and y components of
     // every 3-vector operation in ONE packed instruction (v_pk_{mul,add,fma}_f32 round each half exactly like the
     // scalar instruction; nothing is contracted): in this kernel every VALU instruction costs about one 4-cycle
-    // issue slot whatever its class (measured in place: profiles/r02_insitu_costs.md), so the instruction COUNT
+    // issue slot whatever its class (measured in place: profiles/history/r02_insitu_costs.md), so the instruction COUNT
     // is what the bounce costs and a packed pair is two operations for one slot.
     const f2 oxy = s.oxy, dxy = s.dxy;
     const f2 hxy = oxy + dxy * tmin;                           // :513-518  h = o + d*t (mul, then add)

@@ -3,7 +3,7 @@
 does not guard for inline-asm readers: a TRANS result (v_rsq / v_rcp / v_sqrt / v_exp / v_log / v_sin / v_cos, f32 or f16; the
 float64 forms are not TRANS-pipe instructions but are listed too, conservatively) read by the very next instruction when that is
 a non-TRANS VALU instruction.  hipcc separates such pairs of its own instructions by at least one wait state; a hit here is an
-inline-asm reader scheduled right behind the producer (round 2 met one: profiles/r02_insitu_costs.md).  Exit code 1 on a hit."""
+inline-asm reader scheduled right behind the producer (round 2 met one: profiles/history/r02_insitu_costs.md).  Exit code 1 on a hit."""
 import re, sys
 trans = re.compile(r"^v_(rsq|rcp|sqrt|exp|log|sin|cos)(_iflag|_legacy)?_(f32|f16|f64)")
 vreg = re.compile(r"\bv\[(\d+):(\d+)\]|\bv(\d+)\b")

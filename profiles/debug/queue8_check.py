@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Round 3: the rewritten sample-queue kernel (pt_queue.h) -- correctness against the oracle on small frames (frame bits and
 traced-segment counts), then C2 / C5 / C5 with roulette timed against the pixels-per-wave knob.  (Round 3 also timed the round-2
-queue here, through APT_OLD_QUEUE=1; that kernel was removed in round 4 -- profiles/r03_queue_check.jsonl keeps its numbers.)   python profiles/debug/queue8_check.py [--skip-check] > gpurun_out/queue8.jsonl"""
+queue here, through APT_OLD_QUEUE=1; that kernel was removed in round 4 -- profiles/history/r03_queue_check.jsonl keeps its numbers.)   python profiles/debug/queue8_check.py [--skip-check] > gpurun_out/queue8.jsonl"""
 import argparse, json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np

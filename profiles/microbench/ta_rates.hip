@@ -1,6 +1,6 @@
 // ta_rates.hip -- what a vector-memory load costs the CU's address path (TA / vL1D) on gfx950 as a function of the number of
 // ACTIVE lanes, the access width and the address pattern.  The grid walk of the large-scene path (pt_trace.h grid_segment) runs
-// with ~30 % of its lanes active and its TA 90 % busy (profiles/r03_grid_ta_pmc.json): whether a load of a half-empty wave costs
+// with ~30 % of its lanes active and its TA 90 % busy (profiles/history/r03_grid_ta_pmc.json): whether a load of a half-empty wave costs
 // half decides whether filling the lanes can pay.
 //   hipcc -O3 --offload-arch=gfx950 ta_rates.hip -o ta_rates && ./ta_rates
 // Every wave runs 4 independent address chains (an LCG per chain, no dependence on loaded data), 8 waves per SIMD, 8 blocks of

@@ -7,7 +7,7 @@ reference's own pipeline, GPU vs CPU restatement, every one of the 530,841,600 p
   fused frame kernel (the benchmarked one, counter-RNG rays)  : device vs oracle.render_frame, every pixel
 Checker code (oracle) is used here as the checker only.  ~70 s on 128 host threads, ~40 GB of host memory.
 Run directly (python tests/full_size_c2_parity.py) or through pytest with APT_FULL_PARITY=1
-(tests/test_gpu_parity.py::test_full_size_c2_parity); the round-1 log is profiles/r01_c2_full_parity.log."""
+(tests/test_gpu_parity.py::test_full_size_c2_parity); the round-1 log is profiles/history/r01_c2_full_parity.log."""
 import hashlib, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch

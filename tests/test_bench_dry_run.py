@@ -175,3 +175,43 @@ def test_a_run_that_dies_says_why_on_the_json_line():
     assert len(lines) == 1, r.stdout
     out = json.loads(lines[0])
     assert out["value"] is None and out["error"] and out["unit"] == "Mray/s" and out["n_gpus"] == 1
+
+
+def test_multi_rank_profile_summary_reports_valu_occupancy_and_hbm_rate_per_rank(tmp_path):
+    """the first 8-GPU run must report VALU occupancy and HBM GB/s per rank without a code change.
+    profiles/run_profile_multi.sh leaves <out>/stats/rank<r>/ and <out>/pmc<i>/rank<r>/; profiles/multi_summary.py condenses them with
+    bench.py's own formulas.  Stand-in CSVs for two ranks (no GPU): the figures come out per rank, the first launch of each process is
+    dropped, rank 1's slower band shows."""
+    sys.path.insert(0, os.path.join(ROOT, "profiles"))
+    import multi_summary
+    k = "void (anonymous namespace)::render_frame_kernel<0, 0, 8, false, true>(float const*, ...)"
+    seg = 2 ** 21 * 4 * 256 * 8
+    (tmp_path / "bench.json").write_text(json.dumps({"config": {"segments_per_gpu": seg}}) + "\n")
+    groups = [("FETCH_SIZE",), ("WRITE_SIZE",), ("SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU", "GRBM_GUI_ACTIVE")]
+    for r, ms in ((0, 80.0), (1, 100.0)):
+        cyc = ms * 1e6 * 2.0                                               # 2 GHz
+        table = {"FETCH_SIZE": 500.0, "WRITE_SIZE": 30000.0, "GRBM_GUI_ACTIVE": 8 * cyc, "SQ_INSTS_VALU": 0.2 * cyc * 1024,
+                 "SQ_ACTIVE_INST_VALU": 1e9, "SQ_THREAD_CYCLES_VALU": 60e9, "SQ_WAVE_CYCLES": cyc * 1024, "SQ_WAVES": 1e6}
+        d = tmp_path / "stats" / f"rank{r}" / "host"
+        d.mkdir(parents=True)
+        (d / "1_kernel_stats.csv").write_text('"Name","Calls","TotalDurationNs","AverageNs","Percentage"\n"%s",7,%d,%d,98.5\n' % (k, 7 * ms * 1e6, ms * 1e6))
+        for i, grp in enumerate(groups):
+            d = tmp_path / f"pmc{i + 1}" / f"rank{r}" / "host"
+            d.mkdir(parents=True)
+            with open(d / "1_counter_collection.csv", "w") as f:
+                f.write("Dispatch_Id,Kernel_Name,Counter_Name,Counter_Value\n")
+                for c in grp:
+                    f.write('1,"%s",%s,%f\n' % (k, c, 7e15))            # the process's first launch: dropped
+                    for disp in (2, 3):
+                        f.write('%d,"%s",%s,%f\n' % (disp, k, c, table[c]))
+            with open(d / "1_kernel_trace.csv", "w") as f:
+                f.write("Dispatch_Id,Kernel_Name,Start_Timestamp,End_Timestamp\n")
+                f.write('1,"%s",0,999999999\n2,"%s",0,%d\n3,"%s",0,%d\n' % (k, k, ms * 1e6, k, ms * 1e6))
+    ranks = multi_summary.main(str(tmp_path), 2)
+    assert [s["avg_ms"] for s in ranks] == [80.0, 100.0] and all(s["calls"] == 7 for s in ranks)
+    for s, ms in zip(ranks, (80.0, 100.0)):
+        assert s["traffic_bytes_per_launch"] == 2 * 500 * 1024 + 30000 * 1024
+        assert s["hbm_gbps"] == round(s["traffic_bytes_per_launch"] / (ms * 1e6), 3)
+        assert s["valu_insts_per_simd_cycle"] == 0.2 and s["waves_per_simd"] == 4.0 and s["lane_activity"] == 0.9375 and s["effective_clock_ghz"] == 2.0
+    out = json.loads((tmp_path / "summary.json").read_text())
+    assert out["n_gpus"] == 2 and out["segments_per_gpu"] == seg and len(out["ranks"]) == 2

@@ -1,5 +1,5 @@
 """CPU: the generated gfx950 ISA has no TRANS result read by the very next VALU instruction.  hipcc guards that hazard for its
-own instructions, not for an inline-asm reader; round 2 met one (profiles/r02_insitu_costs.md) -- the results stayed bit-exact
+own instructions, not for an inline-asm reader; round 2 met one (profiles/history/r02_insitu_costs.md) -- the results stayed bit-exact
 through the exact fallback, so only this scan (and the exact_reruns statistic on the GPU) can see it."""
 import os
 import shutil
