@@ -640,8 +640,8 @@ __global__ __launch_bounds__(kBlock) void decode_color_kernel8(const float *__re
     const uint64_t n_total = npix * 4 * samples;
     const uint64_t items = 3 * npix, per_block = kBlock / 32;          // (pixel, channel) pairs, channel-major
     const uint64_t rounds = (items + per_block * gridDim.x - 1) / (per_block * gridDim.x);
-    // grid-stride over the (pixel, channel) pairs: a block is a few KB of work per round, so the grid is sized to
-    // the machine and loops (a block per pair-group would be bound by the workgroup dispatch rate)
+    // grid-stride over the (pixel, channel) pairs: a block is a few KB of work per round, so the grid is capped and loops (one round at C2
+    // would be 777 600 workgroups: bound by the dispatch rate, 5.5 TB/s; the cap the host uses, 256 x 1024, reads 6.1)
     for (uint64_t r = 0; r < rounds; ++r) {
     const uint64_t pc = (r * gridDim.x + blockIdx.x) * per_block + (threadIdx.x >> 5);
     const bool valid = pc < items;
@@ -694,6 +694,84 @@ __global__ __launch_bounds__(kBlock) void decode_color_kernel8(const float *__re
         fb[ch * npix + q] = (float)cl;
         if (fb_u8) fb_u8[q * 3 + ch] = (uint8_t)(cl * 255); // :55-57 truncation
     }
+    }
+}
+
+// The same sum with FLOAT4 loads, for small sample counts (8 <= samples <= 32, samples % 4 == 0): 2 lanes per sub-pixel row, lane L owns
+// numpy's accumulators r[4L .. 4L+3] and reads a[8m + 4L .. 8m + 4L + 3] as one float4 per block m of 8 samples; 8 lanes = one (pixel,
+// channel).  With 8 lanes per row a lane of decode_color_kernel8 has ONE dword per load instruction and 1-4 loads per row to cover the
+// latency with: 1.2 / 2.3 TB/s at S = 8 / 16 against 3.2 / 5.0 for this form (profiles/microbench/decode_rates.hip; from S = 64 on the
+// 8-lane form with a larger grid is the faster one: 6.1 TB/s, 0.97 of what a float4 copy reaches on this part).  Same additions in the
+// same order: ((r0+r1)+(r2+r3)) in lane 0, ((r4+r5)+(r6+r7)) in lane 1, their sum through one shuffle (commutative: both lanes hold the
+// same bits), the n % 8 tail in order.
+constexpr int kDecode4Groups = kBlock / 2;   // sub-pixel groups (2 lanes) per block
+constexpr int kDecode4Blocks = 4;            // blocks of 8 samples a row may have: samples <= 32
+__global__ __launch_bounds__(kBlock) void decode_color_kernel4(const float *__restrict__ colors, uint32_t samples, uint64_t npix, LeafProg lp,
+                                                               float *__restrict__ fb, uint8_t *__restrict__ fb_u8) {
+    __shared__ float stack_lds[kMaxStack * kDecode4Groups];
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t L = threadIdx.x & 1u;
+    const uint32_t sub = (threadIdx.x >> 1) & 3u;
+    const uint32_t slot = threadIdx.x >> 1;
+    const uint64_t n_total = npix * 4 * samples;
+    const uint64_t items = 3 * npix, per_block = kBlock / 8;           // (pixel, channel) pairs, channel-major
+    const uint64_t rounds = (items + per_block * gridDim.x - 1) / (per_block * gridDim.x);
+    for (uint64_t r = 0; r < rounds; ++r) {
+        const uint64_t pc = (r * gridDim.x + blockIdx.x) * per_block + (threadIdx.x >> 3);
+        const bool valid = pc < items;
+        const uint64_t ch = valid ? pc / npix : 0, q = valid ? pc % npix : 0;
+        const float *a = colors + ch * n_total + (q * 4 + sub) * samples;
+        float res = 0.0f;
+        uint32_t start = 0;
+        int sp = 0;
+        for (uint32_t leaf = 0; leaf < lp.nleaves; ++leaf) {
+            const uint32_t n = lp.len(leaf), nfull = n & ~7u;
+            // samples <= 32 (the host's condition for this kernel): ONE leaf of at most 4 blocks of 8, all loads issued before the first add
+            // (sixteen float4 in flight -- any leaf -- cost the occupancy more than they hide: 3.2 against 4.7 TB/s at S = 8)
+            float4 v[kDecode4Blocks];
+#pragma unroll
+            for (int m = 0; m < kDecode4Blocks; ++m)                     // wave-uniform guard
+                v[m] = (8u * m < nfull) ? *reinterpret_cast<const float4 *>(a + start + 8u * m + 4u * L) : make_float4(0.f, 0.f, 0.f, 0.f);
+            float4 acc = v[0];
+#pragma unroll
+            for (int m = 1; m < kDecode4Blocks; ++m)
+                if (8u * m < nfull) { acc.x = acc.x + v[m].x; acc.y = acc.y + v[m].y; acc.z = acc.z + v[m].z; acc.w = acc.w + v[m].w; }
+            float s = (acc.x + acc.y) + (acc.z + acc.w);                // (r0+r1)+(r2+r3) resp. (r4+r5)+(r6+r7)
+            s = s + __shfl_xor(s, 1, 64);
+            const uint32_t nt = n - nfull;
+            if (nt) {                                                    // res += a[i] for the n % 8 trailing samples, in order
+                float c[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) c[k] = (4u * L + k < nt) ? a[start + nfull + 4u * L + k] : 0.0f;
+#pragma unroll
+                for (int t = 0; t < 7; ++t)
+                    if ((uint32_t)t < nt) s = s + __shfl(c[t & 3], (int)((lane & ~1u) + (t >> 2)), 64);
+            }
+            start += n;
+            if (lp.nleaves == 1) {
+                res = s;
+            } else {                                                     // pairwise(left) + pairwise(right), innermost first
+                stack_lds[sp * kDecode4Groups + slot] = s;
+                ++sp;
+                for (uint32_t m = 0; m < lp.ncomb(leaf); ++m) {
+                    --sp;
+                    const float x = stack_lds[(sp - 1) * kDecode4Groups + slot], y = stack_lds[sp * kDecode4Groups + slot];
+                    stack_lds[(sp - 1) * kDecode4Groups + slot] = x + y;
+                }
+            }
+        }
+        if (lp.nleaves > 1) res = stack_lds[slot];
+        const float mean = res / (float)samples;              // np.mean: float32 sum / count
+        const int gbase = (int)(lane & ~7u);
+        double acc64 = 0.0;                                    // data_visualization.py:38 sum_color = zeros (float64)
+#pragma unroll
+        for (int sq = 0; sq < 4; ++sq) acc64 = acc64 + (double)__shfl(mean, gbase + sq * 2, 64); // :41-45
+        const double v64 = acc64 / 4;                          // :46
+        const double cl = v64 < 0 ? 0 : (v64 > 1 ? 1 : v64);   // :54
+        if (valid && (lane & 7u) == 0) {
+            fb[ch * npix + q] = (float)cl;
+            if (fb_u8) fb_u8[q * 3 + ch] = (uint8_t)(cl * 255); // :55-57 truncation
+        }
     }
 }
 

@@ -823,11 +823,18 @@ int apt_decode_color_band(const apt_render_params *p, void *stream, const float 
     if ((rc = make_leaf_prog(p->samples, lp))) return rc;
     const uint64_t npix = pixel_count;                    // the band is decoded like an image of pixel_count pixels
     const bool wide = p->samples >= 8;                    // 8 lanes per sub-pixel row: coalesced loads
-    const uint64_t lanes = npix * 3 * 4 * (wide ? 8 : 1);
+    // few samples: 2 lanes per row with float4 loads (decode_color_kernel4); every row then starts at a multiple of 16 bytes from `colors`
+    const bool quad = wide && p->samples <= 8u * kDecode4Blocks && p->samples % 4 == 0 && ((uintptr_t)colors & 15u) == 0;
+    const uint64_t lanes = npix * 3 * 4 * (quad ? 2 : (wide ? 8 : 1));
     const uint64_t blocks = (lanes + kBlock - 1) / kBlock;
     if (blocks > 0x7fffffffull) return fail(APT_ERR_ARG, "band too large for one launch%s");
-    if (wide)
-        hipLaunchKernelGGL(decode_color_kernel8, dim3((unsigned)std::min<uint64_t>(blocks, 256u * 64u)), dim3(kBlock), 0, (hipStream_t)stream, colors,
+    // grid caps measured on the C2 buffer (profiles/microbench/decode_rates.hip): 8-lane form 4.9 / 5.4 / 6.1 / 5.5 TB/s at 256 x 64 / 256 / 1024 /
+    // one round for S = 64 (S = 256: 5.1 / 5.5 / 5.6 / 5.7; below 64 samples the smaller grid wins); float4 form 4.3 / 6.1 / 4.6 TB/s at S = 8 / 16 / 32 with its cap of 256 x 256 (8-lane form: 1.2 / 2.3 / 4.1)
+    if (quad)
+        hipLaunchKernelGGL(decode_color_kernel4, dim3((unsigned)std::min<uint64_t>(blocks, 256u * 256u)), dim3(kBlock), 0, (hipStream_t)stream, colors,
+                           p->samples, npix, lp, fb, fb_u8);
+    else if (wide)
+        hipLaunchKernelGGL(decode_color_kernel8, dim3((unsigned)std::min<uint64_t>(blocks, p->samples >= 64 ? 256u * 1024u : 256u * 256u)), dim3(kBlock), 0, (hipStream_t)stream, colors,
                            p->samples, npix, lp, fb, fb_u8);
     else
         hipLaunchKernelGGL(decode_color_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, colors,
