@@ -587,7 +587,7 @@ def main():
         traffic, traffic_tag = None, None     # the committed PMC passes are of the N = 1 C2 launch
     traffic_extra = {}
     if live is not None:                      # measured in this very run: those are the figures
-        traffic_extra = {k: v for k, v in live.items() if k != "traffic"}
+        traffic_extra = {k: v for k, v in live.items() if k not in ("traffic", "error")}   # ("error": no pass ran at all -> the *_probe_error keys below)
         if "traffic" in live:
             traffic, traffic_tag = live["traffic"], None
             traffic_extra["traffic_over_algorithmic"] = round(live["traffic"] / (W * H * 15 + 512), 4)
