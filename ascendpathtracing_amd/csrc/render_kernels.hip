@@ -87,6 +87,10 @@ TraceArgs make_trace_args(const apt_render_params *p, const Launch &ls) {
     return ta;
 }
 
+// Buffer mode takes the two-paths-per-lane kernel from this many paths on: below it the one-path kernel's twice as many workgroups fill the
+// chip better (C1, the reference's own CPU-runnable configuration, is 262 144 paths = 1024 workgroups of it: launch-bound either way).
+constexpr uint64_t kTwoPathBufferMin = 1ull << 20;
+
 template <int MODE, int SC>
 void launch_paths(bool retire, dim3 grid, hipStream_t st, const float *rays, const float *sph, float *colors,
                   uint64_t n, uint64_t b, uint64_t c, const TraceArgs &ta) {
@@ -145,7 +149,11 @@ int do_render_paths(const Launch &ls, const apt_render_params *p, void *stream, 
         rays -= b;
         colors -= b;
     }
-    if (retire && ns8) { // wave-level queue: one wave per kQueueChunk consecutive paths
+    if (ns8 && !retire && ta.rr_start == 0 && c >= kTwoPathBufferMin) {   // a large range of the reference scene, every segment traced: two paths per lane
+        const dim3 grid2((unsigned)((c + 2 * kBlock - 1) / (2 * kBlock)));
+        if (p->mode == APT_MODE_ORACLE) hipLaunchKernelGGL((render_paths2_kernel<kModeOracle>), grid2, dim3(kBlock), 0, st, rays, spheres, colors, n, b, c, ta);
+        else hipLaunchKernelGGL((render_paths2_kernel<kModeKernel>), grid2, dim3(kBlock), 0, st, rays, spheres, colors, n, b, c, ta);
+    } else if (retire && ns8) { // wave-level queue: one wave per kQueueChunk consecutive paths
         const uint64_t waves = (c + kQueueChunk - 1) / kQueueChunk;
         const dim3 qgrid((unsigned)((waves + kBlock / 64 - 1) / (kBlock / 64)));
         if (p->mode == APT_MODE_ORACLE) hipLaunchKernelGGL((render_paths_queue_kernel<kModeOracle>), qgrid, dim3(kBlock), 0, st, rays, spheres, colors, n, b, c, ta);

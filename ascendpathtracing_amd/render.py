@@ -25,6 +25,13 @@ def _dev_f32(t, name, numel=None):
     return ctypes.c_void_p(t.data_ptr())
 
 
+def _buffer_paths(params):
+    """Paths per plane of the ray / colour buffers of a buffer-mode call: the whole image, or the range alone with band-relative buffers."""
+    if (params.flags & _lib.APT_FLAG_BAND_BUFFERS) and params.path_count:
+        return params.path_count
+    return params.num_paths
+
+
 def sphere_floats(num_spheres):
     """Length of the zero-padded [10][Ns] table (512-byte multiple, gen_data.py:120-127)."""
     return (num_spheres * 10 + 127) // 128 * 128
@@ -88,7 +95,7 @@ class Context:
 
     def render_do_ex(self, params, stream, rays, spheres, colors):
         require_gpu()
-        n = params.num_paths
+        n = _buffer_paths(params)
         check(lib().apt_context_render_do_ex(self._h, ctypes.byref(params), _stream_handle(stream), _dev_f32(rays, "rays", 6 * n),
                                              _dev_f32(spheres, "spheres", sphere_floats(params.num_spheres)),
                                              _dev_f32(colors, "colors", 3 * n)), "apt_context_render_do_ex")
@@ -203,9 +210,10 @@ def check_device_status(stream=None):
 
 
 def render_do_ex(params: RenderParams, stream, rays, spheres, colors):
-    """Run-time-parameter form of render_do: rays [6][N], spheres [10][Ns] padded, colors [3][N]."""
+    """Run-time-parameter form of render_do: rays [6][N], spheres [10][Ns] padded, colors [3][N] (with APT_FLAG_BAND_BUFFERS: planes of
+    path_count floats holding only the range)."""
     require_gpu()
-    n = params.num_paths
+    n = _buffer_paths(params)
     check(lib().render_do_ex(ctypes.byref(params), _stream_handle(stream), _dev_f32(rays, "rays", 6 * n),
                              _dev_f32(spheres, "spheres", sphere_floats(params.num_spheres)),
                              _dev_f32(colors, "colors", 3 * n)), "render_do_ex")
