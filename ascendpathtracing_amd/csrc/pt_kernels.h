@@ -43,8 +43,9 @@ __global__ __launch_bounds__(kBlock, SC == kSceneGrid ? APT_GRID_WAVES : 1) void
 // ---- kernel: rays from a buffer, TWO paths per lane (the reference scene, every segment traced, no roulette; large ranges) ----------
 // The drop-in boundary at scale (render_do_ex on a C2-sized buffer: the three-kernel form of the reference's exact pipeline): the bounce of
 // the fused frame kernel's headline form (pt_trace2.h: every register pair holds (A, B) of one quantity, the whole shading step packed,
-// 145.5 instead of ~168 issue slots per path and bounce).  A block takes 2 * kBlock consecutive paths, thread t the paths t and t + kBlock of
-// them: both halves load and store coalesced.  Lanes past the end of the range trace a copy of a valid path and store nothing.
+// 145.5 issue slots per path and bounce).  A block takes kPaths2Pairs runs of 2 * kBlock consecutive paths, thread t the paths t and t + kBlock
+// of a run: both halves load and store coalesced.  Lanes past the end of the range trace a copy of a valid path and store nothing.
+constexpr int kPaths2Pairs = 2;   // path pairs a thread of render_paths2_kernel traces one after the other (the block's set-up -- scene to SGPRs and LDS, key constants -- is ~6 % of one pair's 8 bounces)
 template <int MODE>
 __global__ __launch_bounds__(kBlock, APT_TWO_WAVES) void render_paths2_kernel(const float *__restrict__ rays, const float *__restrict__ sph,
                                                                               float *__restrict__ colors, uint64_t n_total, uint64_t begin,
@@ -52,19 +53,24 @@ __global__ __launch_bounds__(kBlock, APT_TWO_WAVES) void render_paths2_kernel(co
     __shared__ float4 tab[kTab8Floats4];
     Scene8 sc;
     const Tab8 tab8 = load_scene8(sph, sc, tab);           // (with the (1,1,1) entry the two-path bounce multiplies a finished path's throughput by)
-    const uint64_t local = (uint64_t)blockIdx.x * (2 * kBlock) + threadIdx.x;
-    const bool va = local < count, vb = local + kBlock < count;
-    const uint64_t pa = begin + (va ? local : 0), pb = vb ? begin + local + kBlock : pa;
-    PathPair pp;                                           // CopyIn: render.cpp:82-101
-    pp.ox = f2{rays[pa], rays[pb]}; pp.oy = f2{rays[n_total + pa], rays[n_total + pb]}; pp.oz = f2{rays[2 * n_total + pa], rays[2 * n_total + pb]};
-    pp.dx = f2{rays[3 * n_total + pa], rays[3 * n_total + pb]}; pp.dy = f2{rays[4 * n_total + pa], rays[4 * n_total + pb]};
-    pp.dz = f2{rays[5 * n_total + pa], rays[5 * n_total + pb]};
-    pp.rx = pp.ry = pp.rz = f2{1.0f, 1.0f};                // render.cpp:116-121
-    trace2_ns8<MODE>(sc, tab8, pp, ta, sc.planes);
-    const Gain3 gain = load_gain(sph, ta);                 // render.cpp:194-196, CopyOut :210-223
-    if (va) { colors[pa] = pp.rx.x * gain.r; colors[n_total + pa] = pp.ry.x * gain.g; colors[2 * n_total + pa] = pp.rz.x * gain.b; }
-    if (vb) { colors[pb] = pp.rx.y * gain.r; colors[n_total + pb] = pp.ry.y * gain.g; colors[2 * n_total + pb] = pp.rz.y * gain.b; }
-    count_traced(ta, ((va ? 1u : 0u) + (vb ? 1u : 0u)) * ta.depth);
+    const Gain3 gain = load_gain(sph, ta);                 // render.cpp:194-196
+    uint32_t traced = 0;
+    for (int it = 0; it < kPaths2Pairs; ++it) {
+        const uint64_t local = ((uint64_t)blockIdx.x * kPaths2Pairs + it) * (2 * kBlock) + threadIdx.x;
+        if (__builtin_amdgcn_readfirstlane((int)(((uint64_t)blockIdx.x * kPaths2Pairs + it) * (2 * kBlock) >= count))) break;   // (wave-uniform: nothing left for this block)
+        const bool va = local < count, vb = local + kBlock < count;
+        const uint64_t pa = begin + (va ? local : 0), pb = vb ? begin + local + kBlock : pa;
+        PathPair pp;                                       // CopyIn: render.cpp:82-101
+        pp.ox = f2{rays[pa], rays[pb]}; pp.oy = f2{rays[n_total + pa], rays[n_total + pb]}; pp.oz = f2{rays[2 * n_total + pa], rays[2 * n_total + pb]};
+        pp.dx = f2{rays[3 * n_total + pa], rays[3 * n_total + pb]}; pp.dy = f2{rays[4 * n_total + pa], rays[4 * n_total + pb]};
+        pp.dz = f2{rays[5 * n_total + pa], rays[5 * n_total + pb]};
+        pp.rx = pp.ry = pp.rz = f2{1.0f, 1.0f};            // render.cpp:116-121
+        trace2_ns8<MODE>(sc, tab8, pp, ta, sc.planes);
+        if (va) { colors[pa] = pp.rx.x * gain.r; colors[n_total + pa] = pp.ry.x * gain.g; colors[2 * n_total + pa] = pp.rz.x * gain.b; }   // CopyOut :210-223
+        if (vb) { colors[pb] = pp.rx.y * gain.r; colors[n_total + pb] = pp.ry.y * gain.g; colors[2 * n_total + pb] = pp.rz.y * gain.b; }
+        traced += ((va ? 1u : 0u) + (vb ? 1u : 0u)) * ta.depth;
+    }
+    count_traced(ta, traced);
 }
 
 // ---- kernel: rays from a buffer, with active-ray compaction (APT_FLAG_RETIRE, Ns == 8) ------------

@@ -150,7 +150,8 @@ int do_render_paths(const Launch &ls, const apt_render_params *p, void *stream, 
         colors -= b;
     }
     if (ns8 && !retire && ta.rr_start == 0 && c >= kTwoPathBufferMin) {   // a large range of the reference scene, every segment traced: two paths per lane
-        const dim3 grid2((unsigned)((c + 2 * kBlock - 1) / (2 * kBlock)));
+        const uint64_t per_block = 2ull * kBlock * kPaths2Pairs;
+        const dim3 grid2((unsigned)((c + per_block - 1) / per_block));
         if (p->mode == APT_MODE_ORACLE) hipLaunchKernelGGL((render_paths2_kernel<kModeOracle>), grid2, dim3(kBlock), 0, st, rays, spheres, colors, n, b, c, ta);
         else hipLaunchKernelGGL((render_paths2_kernel<kModeKernel>), grid2, dim3(kBlock), 0, st, rays, spheres, colors, n, b, c, ta);
     } else if (retire && ns8) { // wave-level queue: one wave per kQueueChunk consecutive paths
