@@ -412,3 +412,22 @@ def test_contexts_are_independent_and_thread_safe(apt):
     assert not errs
     h.apt_context_destroy(a)
     h.apt_context_destroy(b)
+
+
+def test_grid_flags_reads_exactly_the_header_whatever_the_buffer_type(apt):
+    """grid_flags() sliced 32 ELEMENTS of whatever it was given and apt_grid_flags copies 128 BYTES: a uint8 view or a short
+    buffer was a host out-of-bounds read.  Now: any element type gives the same flags, a buffer shorter than a header raises."""
+    import torch
+    ns = 60
+    scene = apt.gen_data.gen_scene(ns, seed=2)
+    g = apt.gen_data.build_grid(scene, ns)
+    want = apt.gen_data.grid_flags(g, ns)
+    assert want == apt.APT_FLAG_GRID_SLOTS
+    assert apt.gen_data.grid_flags(g.view(np.uint8), ns) == want
+    assert apt.gen_data.grid_flags(g.view(np.uint8)[:128], ns) == want
+    assert apt.gen_data.grid_flags(g.view(np.uint16), ns) == want
+    assert apt.gen_data.grid_flags(torch.from_numpy(g.view(np.int32)), ns) == want          # (a CPU tensor takes the tensor path)
+    assert apt.gen_data.grid_flags(g, ns + 1) == 0                                          # another scene's grid earns nothing
+    for short in (g[:31], g.view(np.uint8)[:127], torch.from_numpy(g.view(np.int32))[:31]):
+        with pytest.raises(apt.AptError, match="shorter than a grid header"):
+            apt.gen_data.grid_flags(short, ns)
